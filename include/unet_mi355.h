@@ -1,0 +1,179 @@
+/* libunet_mi355 - C ABI of the MI355X (gfx950) U-Net hot path.
+ *
+ * The reference (hakkini2/UNet) has no FFI of its own: train.py reaches its arithmetic
+ * through the Python surface of MONAI / PyTorch.  Every entry point below therefore cites
+ * the reference call site whose work it takes over; the Python package `unet_amd` binds
+ * these symbols with ctypes.
+ *
+ * Conventions
+ *  - plain C types only; device buffers are raw pointers (torch `tensor.data_ptr()`),
+ *    `stream` is a hipStream_t passed as void* (0 = default stream);
+ *  - every function returns 0 on success, a negative code otherwise, and
+ *    mi_last_error() then returns a thread-local message;
+ *  - nothing allocates or frees device memory and nothing synchronises the stream:
+ *    callers pass workspaces sized by the matching *_bytes() query;
+ *  - activations are channels-last: element (n, z, y, x, ch) of a tensor lives at
+ *    ((((n*D + z)*H + y)*W + x) * pitch + coff + ch); dtype 0 = fp32, 1 = bf16.
+ *    One-channel tensors (image, logits, labels) are fp32 in PyTorch's contiguous layout.
+ */
+#ifndef UNET_MI355_H
+#define UNET_MI355_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* mi_last_error(void);
+int mi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Whole-network engine.
+ * Replaces: monai.networks.nets.UNet construction (reference/train.py:78-86), model(inputs)
+ * (train.py:115, 140) and the autograd backward of loss.backward() (train.py:117).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mi_unet_cfg {
+    int32_t spatial_dims;      /* 2 | 3 */
+    int32_t in_channels;       /* 1 */
+    int32_t out_channels;      /* 1 */
+    int32_t n_levels;          /* len(channels) >= 2 */
+    int32_t channels[8];       /* multiples of 16 */
+    int32_t strides[8];        /* all 2 */
+    int32_t num_res_units;     /* >= 1 */
+    float dropout;             /* probability, 0 <= p < 1 */
+    int32_t dtype;             /* storage / MFMA input type of the hidden activations: 0 fp32, 1 bf16 */
+    int32_t batch;             /* images per call */
+    int32_t dims[3];           /* (D,H,W) of the input; D = 1 in 2-D; each divisible by 2^(n_levels-1) */
+    int32_t with_backward;     /* 1: plan also holds the backward pass */
+} mi_unet_cfg;
+
+typedef struct mi_unet mi_unet;   /* opaque plan */
+
+typedef struct mi_param_info {
+    char name[160];            /* state_dict key, e.g. "model.0.conv.unit0.conv.weight" */
+    int32_t ndim;
+    int32_t shape[5];
+    int64_t numel;
+    int64_t offset;            /* element offset inside the flat fp32 parameter / gradient buffers */
+    int32_t bucket;            /* gradient bucket: 0 decoder, 1 bottom, 2 encoder (backward completion order) */
+} mi_param_info;
+
+int mi_unet_create(const mi_unet_cfg* cfg, mi_unet** out);
+void mi_unet_destroy(mi_unet* u);
+int mi_unet_num_params(const mi_unet* u);                     /* parameter tensors (63 for the reference nets) */
+int mi_unet_param_info(const mi_unet* u, int i, mi_param_info* info);   /* i in state_dict order */
+int64_t mi_unet_param_floats(const mi_unet* u);               /* length of the flat buffers */
+size_t mi_unet_workspace_bytes(const mi_unet* u);
+int mi_unet_bucket_range(const mi_unet* u, int bucket, int64_t* offset, int64_t* count);
+double mi_unet_flops(const mi_unet* u, int backward);          /* 2*MAC of the convolutions of one call */
+int mi_unet_num_steps(const mi_unet* u, int backward);         /* kernel launches per call (host logic check) */
+
+/* logits[b,1,...] = UNet(x[b,1,...]); `training` != 0 enables dropout (seeded, stateless).  */
+int mi_unet_forward(mi_unet* u, const float* params, const float* x, float* logits, void* workspace,
+                    int training, uint64_t seed, void* stream);
+/* grads (flat fp32, same layout as params) of the forward that last used `workspace`.
+ * `training` and `seed` must repeat the forward's values (the dropout mask is recomputed, not stored).
+ * bucket < 0: whole backward; otherwise buckets must be run in order 0,1,2. */
+int mi_unet_backward(mi_unet* u, const float* params, const float* dlogits, float* grads, void* workspace,
+                     int training, uint64_t seed, int bucket, void* stream);
+
+/* Per-launch timing: when enabled every kernel launch of the engine is bracketed by HIP events on
+ * its stream.  mi_unet_prof_collect() synchronises those events and adds the elapsed times to the
+ * per-step accumulators read by mi_unet_step_info(). */
+int mi_unet_prof_enable(mi_unet* u, int on);
+int mi_unet_prof_collect(mi_unet* u);
+int mi_unet_prof_reset(mi_unet* u);
+typedef struct mi_step_info {
+    char layer[96];            /* which layer of the network the launch belongs to */
+    char kernel[96];           /* kernel (template instance) it runs */
+    double work;               /* algorithmic flops (convolutions) or bytes (everything else) per launch */
+    int32_t work_is_flops;
+    double total_ms;           /* accumulated by mi_unet_prof_collect */
+    int64_t launches;
+} mi_step_info;
+int mi_unet_step_info(const mi_unet* u, int backward, int i, mi_step_info* info);
+
+/* ------------------------------------------------------------------------------------------
+ * Loss / metric.  Replaces DiceCELoss(to_onehot_y=False, sigmoid=True)(outputs, labels) and its
+ * backward (train.py:88,116-117,142), labels[labels==2]=1 (train.py:112-113,137-138), the
+ * sigmoid + >=0.5 post transform and DiceMetric (train.py:89,92,145-152) and
+ * calculate_dice_score (utils/utils.py:11-44).  Label dtype: 0 fp32, 1 uint8, 2 int64, 3 int32.
+ * ------------------------------------------------------------------------------------------ */
+int mi_dice_ce_loss_fwd(const float* logits, const void* target, int target_dtype, int fold2, int nb,
+                        int64_t npix, float smooth_nr, float smooth_dr, float lambda_dice, float lambda_ce,
+                        float* sums /* [nb][4] scratch, kept for backward */, float* loss /* [1] */,
+                        float* loss_accum /* optional running sum */, void* stream);
+int mi_dice_ce_loss_bwd(const float* logits, const void* target, int target_dtype, int fold2, int nb,
+                        int64_t npix, float smooth_nr, float smooth_dr, float lambda_dice, float lambda_ce,
+                        const float* sums, const float* grad_out /* optional device scalar */, float grad_scale,
+                        float* dlogits, void* stream);
+int mi_dice_counts(const float* pred, int pred_is_binary, float thresh, const void* target, int target_dtype,
+                   int fold2, int nb, int64_t npix, uint64_t* counts /* [nb][4] tp,fp,fn,tn */, void* stream);
+int mi_fold_labels(void* target, int target_dtype, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimizer.  Replaces torch.optim.AdamW(...).step() (train.py:90,118) on the flat buffers.
+ * ------------------------------------------------------------------------------------------ */
+int mi_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
+                  void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Sliding-window inference helpers.  Replace the crop / blend arithmetic of
+ * monai.inferers.sliding_window_inference (train.py:140); window placement is host logic.
+ * `starts` is a device array [nwin][3] of window origins in the padded image.
+ * ------------------------------------------------------------------------------------------ */
+int mi_sw_gather(const float* image, float* windows, const int32_t* starts, int nwin, int win0, int nwin_launch,
+                 int nb, const int32_t img[3], const int32_t roi[3], const int32_t pad_lo[3], float cval,
+                 void* stream);
+int mi_sw_blend(const float* win_out, float* out, const int32_t* starts, int nwin, int nb, const int32_t img[3],
+                const int32_t roi[3], const int32_t pad_lo[3], void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Single operators (the engine is built from these; exported for operator-level parity tests
+ * and for callers that assemble other networks).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mi_conv_desc {
+    int32_t ndim;        /* 2 | 3 */
+    int32_t transposed;  /* 0 conv (pad=(k-1)/2) | 1 transposed conv k3 s2 p1 output_padding 1 */
+    int32_t ksize;       /* 3 | 1 */
+    int32_t stride;      /* 1 | 2 */
+    int32_t cin, cout;   /* multiples of 16 */
+    int32_t nb;
+    int32_t in_dims[3];  /* (D,H,W) of the layer input */
+    int32_t dtype;       /* 0 fp32 | 1 bf16 */
+} mi_conv_desc;
+
+typedef struct mi_tensor {
+    void* ptr; int32_t pitch; int32_t coff;
+    void* ptr2; int32_t pitch2; int32_t coff2; int32_t c1;  /* optional: channels >= c1 come from ptr2 */
+} mi_tensor;
+
+/* torch weight layout in `w`: conv [cout][cin][k..], transposed conv [cin][cout][k..]; fp32 */
+size_t mi_conv_packed_bytes(const mi_conv_desc* d);
+int mi_conv_pack(const mi_conv_desc* d, int dgrad, const float* w, void* packed, void* stream);
+/* F.conv{2,3}d / F.conv_transpose{2,3}d: y = conv(x) (+bias) (+addend); stats (optional) receives
+ * per-(image, slot, channel) sum and sum of squares of the bias-free result ([nb][8][cout][2], pre-zeroed) */
+int mi_conv_forward(const mi_conv_desc* d, const mi_tensor* x, const void* packed, const float* bias,
+                    const mi_tensor* y, const mi_tensor* addend, float* stats, void* stream);
+int mi_conv_dgrad(const mi_conv_desc* d, const mi_tensor* dy, const void* packed_dgrad, const mi_tensor* dx,
+                  const mi_tensor* addend, void* stream);
+size_t mi_conv_wgrad_workspace_bytes(const mi_conv_desc* d);
+/* dw in the torch layout, db [cout] (conv only; may be NULL) */
+int mi_conv_wgrad(const mi_conv_desc* d, const mi_tensor* x, const mi_tensor* dy, float* dw, float* db,
+                  void* workspace, void* stream);
+
+/* InstanceNorm(eps, no affine) -> Dropout(p) -> PReLU(alpha) (+ residual): MONAI ADN "NDA" */
+int mi_instnorm_prelu_fwd(int dtype, int nb, int64_t npix, int c, const mi_tensor* raw, const float* stats,
+                          const float* alpha, const mi_tensor* res, const mi_tensor* out, float dropout,
+                          uint64_t seed, uint32_t layer, void* stream);
+/* bstats: [nb][8][c][2] scratch (zeroed inside); dalpha: device scalar, accumulated */
+int mi_instnorm_prelu_bwd(int dtype, int nb, int64_t npix, int c, const mi_tensor* dy, const mi_tensor* raw,
+                          const float* stats, const float* alpha, float* bstats, float* dalpha,
+                          const mi_tensor* dx, float dropout, uint64_t seed, uint32_t layer, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

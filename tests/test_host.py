@@ -1,0 +1,132 @@
+"""CPU-side checks: the library loads and exports the declared C ABI, the engine's host logic
+(parameter table, flat layout, launch plan, FLOP accounting) agrees with the oracle's module tree,
+and the product fails loudly where it has no GPU."""
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+import torch
+
+import oracle
+import unet_amd
+from unet_amd import _lib
+from unet_amd.nets import _Plan
+
+ROOT = Path(__file__).resolve().parent.parent
+CFG = dict(spatial_dims=2, in_channels=1, out_channels=1, channels=(16, 32, 64, 128, 256), strides=(2, 2, 2, 2),
+           num_res_units=2)
+
+
+def test_library_exports_every_declared_symbol():
+    header = (ROOT / "include" / "unet_mi355.h").read_text()
+    declared = set(re.findall(r"\b(mi_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 30
+    lib = ctypes.CDLL(str(_lib.lib_path()))
+    missing = [n for n in sorted(declared) if not hasattr(lib, n)]
+    assert not missing, missing
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    assert _lib.load().mi_version() >= 100
+
+
+@pytest.mark.parametrize("dims,channels", [(2, (16, 32, 64, 128, 256)), (2, (32, 64, 128, 256, 512)),
+                                           (3, (16, 32, 64, 128, 256)), (2, (16, 32)), (2, (16, 32, 64))])
+def test_param_table_matches_oracle_state_dict(dims, channels):
+    strides = (2,) * (len(channels) - 1)
+    o = oracle.UNet(dims, 1, 1, channels, strides, num_res_units=2)
+    m = unet_amd.UNet(dims, 1, 1, channels, strides, num_res_units=2)
+    table = m._layout()
+    sd = o.state_dict()
+    assert [e[0] for e in table] == list(sd.keys())
+    assert [e[1] for e in table] == [tuple(v.shape) for v in sd.values()]
+    assert list(m.state_dict().keys()) == list(sd.keys())
+    # flat layout: disjoint, 16-byte aligned, inside the buffer, buckets contiguous
+    spans = sorted((e[3], e[3] + e[2]) for e in table)
+    assert all(a % 4 == 0 for a, _ in spans)
+    assert all(spans[i][1] <= spans[i + 1][0] for i in range(len(spans) - 1))
+    assert spans[-1][1] <= m._nfloats
+    (o0, c0), (o1, c1), (o2, c2) = m.gradient_buckets()
+    assert o0 == 0 and o1 == c0 and o2 == c0 + c1 and c0 + c1 + c2 == m._nfloats
+    for name, _, n, off, b in table:
+        lo, cnt = m.gradient_buckets()[b]
+        assert lo <= off and off + n <= lo + cnt
+
+
+def test_same_seed_same_init_as_oracle():
+    torch.manual_seed(123)
+    o = oracle.UNet(**CFG, dropout=0.1)
+    torch.manual_seed(123)
+    m = unet_amd.UNet(**CFG, dropout=0.1)
+    so, sm = o.state_dict(), m.state_dict()
+    assert all(torch.equal(so[k], sm[k]) for k in so)
+    m2 = unet_amd.UNet(**CFG)
+    m2.load_state_dict(so)
+
+
+def test_known_parameter_counts():
+    assert sum(p.numel() for p in unet_amd.UNet(**CFG).parameters()) == 1624844
+    big = dict(CFG, channels=(32, 64, 128, 256, 512))
+    assert sum(p.numel() for p in unet_amd.UNet(**big).parameters()) == 6494716
+    d3 = dict(CFG, spatial_dims=3)
+    assert sum(p.numel() for p in unet_amd.UNet(**d3).parameters()) == 4805534
+    assert len(list(unet_amd.UNet(**CFG).parameters())) == 63
+
+
+def test_flop_accounting_matches_survey_figures():
+    m = unet_amd.UNet(**CFG)
+    p = _Plan(m._cfg_kwargs, 32, (512, 512), 1, True)
+    assert abs(p.flops(False) / 32 / 1e9 - 6.036) < 0.002          # GF per 512x512 slice, forward
+    assert 1.9 < p.flops(True) / p.flops(False) <= 2.0              # dgrad + wgrad (no input gradient)
+    p8 = _Plan(m._cfg_kwargs, 8, (256, 256), 0, True)
+    assert abs(p8.flops(False) / 1e9 - 12.07) < 0.01
+    m3 = unet_amd.UNet(**dict(CFG, spatial_dims=3))
+    p3 = _Plan(m3._cfg_kwargs, 4, (96, 96, 96), 1, True)
+    assert abs(p3.flops(False) / 4 / 1e9 - 9.904) < 0.002
+    # one launch per layer op; every conv of the network appears once in the forward list
+    kernels = [s["kernel"] for s in p.steps(False)]
+    nconv = sum(k.startswith(("igemm_kernel", "c1_s2", "stencil")) for k in kernels)
+    assert nconv == 23 - 4  # the 4 stride-2 residual convs share their unit0 launch
+    assert p.workspace_bytes < 8 << 30
+
+
+def test_constructor_errors_like_monai():
+    with pytest.raises(ValueError):
+        unet_amd.UNet(2, 1, 1, (16,), (2,), num_res_units=2)
+    with pytest.raises(ValueError):
+        unet_amd.UNet(2, 1, 1, (16, 32, 64), (2,), num_res_units=2)
+    with pytest.raises(NotImplementedError):
+        unet_amd.UNet(2, 1, 1, (16, 32), (2,), num_res_units=2, norm="BATCH")
+    with pytest.raises(NotImplementedError):
+        unet_amd.UNet(2, 3, 2, (16, 32), (2,), num_res_units=2)
+
+
+def test_no_cpu_fallback():
+    m = unet_amd.UNet(2, 1, 1, (16, 32), (2,), num_res_units=2)
+    with pytest.raises(RuntimeError, match="GPU"):
+        m(torch.zeros(1, 1, 16, 16))
+    with pytest.raises(RuntimeError, match="GPU"):
+        unet_amd.DiceCELoss(sigmoid=True)(torch.zeros(1, 1, 8, 8), torch.zeros(1, 1, 8, 8))
+    with pytest.raises(RuntimeError, match="GPU"):
+        unet_amd.DiceMetric()(y_pred=torch.zeros(1, 1, 8, 8), y=torch.zeros(1, 1, 8, 8))
+    with pytest.raises(RuntimeError, match="GPU"):
+        unet_amd.sliding_window_inference(torch.zeros(1, 1, 8, 8), (4, 4), 4, lambda a: a)
+    with pytest.raises(ValueError):
+        unet_amd.DiceCELoss(sigmoid=True)(torch.zeros(1, 1, 8, 8), torch.zeros(1, 8, 8))
+    with pytest.raises(AssertionError):
+        unet_amd.DiceCELoss(sigmoid=True)(torch.zeros(1, 1, 8, 8), torch.zeros(1, 1, 8, 4))
+
+
+def test_window_placement_matches_oracle():
+    from oracle.inferer_ref import dense_patch_starts, _scan_interval
+    for img, roi in [((512, 512), (256, 256)), ((96, 80), (64, 64)), ((256, 256), (256, 256)),
+                     ((100, 100, 70), (64, 64, 64)), ((300, 200), (96, 128))]:
+        interval = _scan_interval(img, roi, 0.25)
+        assert unet_amd.window_starts(img, roi, 0.25) == dense_patch_starts(img, roi, interval)
+    assert len(unet_amd.window_starts((512, 512), (256, 256))) == 9
+
+
+def test_volume_grouping_and_checkpoint_names():
+    names = ["liver_3_10.nii.gz", "liver_3_11.nii.gz", "liver_7_2.nii.gz", "liver_7_3.nii.gz"]
+    d = unet_amd.per_volume_dice(names, [0.5, 1.0, float("nan"), 0.8])
+    assert d == {"liver_3": 0.75, "liver_7": 0.8}
+    assert unet_amd.checkpoint_name("Task03_Liver", "pseudo", "2d", "box") == "unet_task03_liver_box_pseudolabels_2D.pth"

@@ -1,0 +1,167 @@
+"""Operator parity on the GPU: every HIP convolution form against torch's CPU convolution on the
+same seeded inputs.  bf16 runs feed the oracle bf16-rounded operands, so products are exact and
+only fp32 accumulation order and the final bf16 store rounding differ."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import bf16_round, from_cl, rel_err, to_cl
+from unet_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+DT = {"fp32": torch.float32, "bf16": torch.bfloat16}
+TOL_OUT = {"fp32": 2e-5, "bf16": 6e-3}      # relative to max |reference|
+TOL_W = {"fp32": 5e-5, "bf16": 2e-4}        # weight gradients are produced in fp32 in both modes
+
+
+def _conv_ref(x, w, b, stride, transposed, nd):
+    if transposed:
+        f = F.conv_transpose2d if nd == 2 else F.conv_transpose3d
+        return f(x, w, b, stride=2, padding=1, output_padding=1)
+    f = F.conv2d if nd == 2 else F.conv3d
+    return f(x, w, b, stride=stride, padding=(w.shape[-1] - 1) // 2)
+
+
+CASES = [
+    # nd, spatial, cin, cout, k, stride, transposed
+    (2, (32, 32), 16, 16, 3, 1, False),
+    (2, (24, 40), 32, 32, 3, 1, False),
+    (2, (16, 16), 64, 128, 3, 1, False),
+    (2, (8, 8), 128, 256, 3, 1, False),
+    (2, (32, 32), 16, 64, 3, 2, False),
+    (2, (16, 48), 32, 128, 3, 2, False),
+    (2, (8, 8), 128, 256, 1, 1, False),
+    (2, (8, 8), 384, 64, 3, 2, True),
+    (2, (16, 16), 64, 16, 3, 2, True),
+    (2, (12, 20), 128, 32, 3, 2, True),
+    (3, (8, 8, 8), 16, 16, 3, 1, False),
+    (3, (4, 8, 12), 32, 64, 3, 1, False),
+    (3, (8, 8, 8), 16, 64, 3, 2, False),
+    (3, (4, 4, 4), 64, 16, 3, 2, True),
+    (3, (4, 4, 4), 32, 64, 1, 1, False),
+]
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "nd%d_%s_%d-%d_k%d_s%d_%s" % (c[0], "x".join(map(str, c[1])), c[2], c[3], c[4], c[5], "T" if c[6] else "C"))
+def test_conv_forward_dgrad_wgrad(dev, mode, case):
+    nd, sp, cin, cout, k, stride, transposed = case
+    dt = DT[mode]
+    g = torch.Generator().manual_seed(1234 + cin * 7 + cout)
+    nb = 2
+    x = torch.randn(nb, cin, *sp, generator=g)
+    wshape = ((cin, cout) if transposed else (cout, cin)) + (k,) * nd
+    w = torch.randn(*wshape, generator=g) / (cin * k ** nd) ** 0.5
+    b = torch.randn(cout, generator=g)
+    if mode == "bf16":
+        x, w = bf16_round(x), bf16_round(w)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    y_ref = _conv_ref(xr, wr, br, stride, transposed, nd)
+    dy = torch.randn(y_ref.shape, generator=g)
+    if mode == "bf16":
+        dy = bf16_round(dy)
+    y_ref.backward(dy)
+
+    xc = to_cl(x, dt, dev)
+    y, stats = ops.conv_forward(xc, w.to(dev), b.to(dev), ksize=k, stride=stride, transposed=transposed, want_stats=True)
+    torch.cuda.synchronize()
+    assert rel_err(from_cl(y), y_ref.detach()) < TOL_OUT[mode]
+    # epilogue statistics: per-(image, channel) sum and sum of squares of the bias-free result
+    nob = (y_ref.detach() - b.view(1, -1, *([1] * nd)))
+    s1 = nob.flatten(2).sum(-1)
+    s2 = (nob * nob).flatten(2).sum(-1)
+    st = stats.cpu().sum(1)
+    assert rel_err(st[..., 0], s1) < 1e-4 and rel_err(st[..., 1], s2) < 1e-4
+
+    dyc = to_cl(dy, dt, dev)
+    dx = ops.conv_dgrad(dyc, w.to(dev), xc.shape, ksize=k, stride=stride, transposed=transposed)
+    assert rel_err(from_cl(dx), xr.grad) < TOL_OUT[mode]
+    # addend in the epilogue (gradient accumulation at a fan-out)
+    dx2 = ops.conv_dgrad(dyc, w.to(dev), xc.shape, ksize=k, stride=stride, transposed=transposed, addend=xc)
+    ref2 = xr.grad + x
+    assert rel_err(from_cl(dx2), ref2) < TOL_OUT[mode]
+
+    dw, db = ops.conv_wgrad(xc, dyc, wshape, ksize=k, stride=stride, transposed=transposed)
+    assert rel_err(dw.cpu(), wr.grad) < TOL_W[mode]
+    if db is not None:
+        assert rel_err(db.cpu(), br.grad) < TOL_W[mode]
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_conv_exact_integer_data(dev, mode):
+    """Small-integer operands make every product and sum exact in both dtypes: any mismatch is an
+    indexing error, not rounding.  Asymmetric weights catch transposed fragments."""
+    dt = DT[mode]
+    g = torch.Generator().manual_seed(7)
+    for (cin, cout, stride, transposed) in [(16, 32, 1, False), (32, 16, 2, False), (48, 16, 2, True), (64, 64, 1, False)]:
+        x = torch.randint(-2, 3, (1, cin, 20, 28), generator=g).float()
+        wshape = ((cin, cout) if transposed else (cout, cin)) + (3, 3)
+        w = torch.randint(-2, 3, wshape, generator=g).float()
+        y_ref = _conv_ref(x, w, None, stride, transposed, 2)
+        assert y_ref.abs().max() < 256  # exactly representable in bf16
+        y = ops.conv_forward(to_cl(x, dt, dev), w.to(dev), None, ksize=3, stride=stride, transposed=transposed)
+        assert torch.equal(from_cl(y), y_ref)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("nd,sp,c", [(2, (32, 32), 16), (2, (20, 12), 64), (3, (4, 6, 8), 32), (2, (16, 16), 256)])
+def test_instnorm_prelu_fwd_bwd(dev, mode, nd, sp, c):
+    dt = DT[mode]
+    g = torch.Generator().manual_seed(99 + c)
+    nb = 3
+    x = torch.randn(nb, c, *sp, generator=g) * 2 + 0.5
+    res = torch.randn(nb, c, *sp, generator=g)
+    dy = torch.randn(nb, c, *sp, generator=g)
+    if mode == "bf16":
+        x, res, dy = bf16_round(x), bf16_round(res), bf16_round(dy)
+    alpha = torch.tensor([0.25])
+    xr = x.clone().requires_grad_(True)
+    ar = alpha.clone().requires_grad_(True)
+    y_ref = F.prelu(F.instance_norm(xr, eps=1e-5), ar) + res
+    y_ref.backward(dy)
+    # statistics as the producing convolution would deliver them (sums split over the 8 slots)
+    s1 = x.flatten(2).sum(-1)
+    s2 = (x * x).flatten(2).sum(-1)
+    stats = torch.zeros(nb, 8, c, 2)
+    stats[:, 0, :, 0], stats[:, 3, :, 1] = s1, s2
+    stats = stats.to(dev)
+    xc, rc, dyc = to_cl(x, dt, dev), to_cl(res, dt, dev), to_cl(dy, dt, dev)
+    y = ops.instnorm_prelu_fwd(xc, stats, alpha.to(dev), res=rc)
+    tol = 2e-5 if mode == "fp32" else 8e-3
+    assert rel_err(from_cl(y), y_ref.detach()) < tol
+    dx, dalpha = ops.instnorm_prelu_bwd(dyc, xc, stats, alpha.to(dev))
+    assert rel_err(from_cl(dx), xr.grad) < (1e-4 if mode == "fp32" else 1e-2)
+    assert abs(float(dalpha.cpu()) - float(ar.grad)) < 1e-4 * max(1.0, abs(float(ar.grad))) * (1 if mode == "fp32" else 50)
+
+
+def test_dropout_statistics_and_mask_replay(dev):
+    """The stateless dropout keeps ~(1-p) of the elements, scales by 1/(1-p), and backward replays
+    the very same mask (gradient is zero exactly where the forward output is zero)."""
+    nb, c, sp = 2, 32, (64, 64)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(nb, c, *sp, generator=g)
+    s1 = x.flatten(2).sum(-1)
+    s2 = (x * x).flatten(2).sum(-1)
+    stats = torch.zeros(nb, 8, c, 2)
+    stats[:, 0, :, 0], stats[:, 0, :, 1] = s1, s2
+    stats = stats.to(dev)
+    alpha = torch.tensor([0.25], device=dev)
+    xc = to_cl(x, torch.float32, dev)
+    p = 0.1
+    y = ops.instnorm_prelu_fwd(xc, stats, alpha, dropout=p, seed=42, layer=3)
+    y0 = ops.instnorm_prelu_fwd(xc, stats, alpha, dropout=0.0)
+    dropped = (y == 0)
+    frac = float(dropped.float().mean())
+    assert abs(frac - p) < 0.01
+    kept = ~dropped
+    assert torch.allclose(y[kept], y0[kept] / (1 - p), rtol=1e-5, atol=1e-6)
+    y_again = ops.instnorm_prelu_fwd(xc, stats, alpha, dropout=p, seed=42, layer=3)
+    assert torch.equal(y, y_again)
+    y_other = ops.instnorm_prelu_fwd(xc, stats, alpha, dropout=p, seed=43, layer=3)
+    assert not torch.equal(y, y_other)
+    dy = torch.ones_like(xc)
+    dx, _ = ops.instnorm_prelu_bwd(dy, xc, stats, alpha, dropout=p, seed=42, layer=3)
+    assert torch.isfinite(dx).all()

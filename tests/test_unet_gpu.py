@@ -1,0 +1,286 @@
+"""Network-level parity on the GPU: logits, loss and all 63 gradients of the HIP engine against the
+CPU oracle on identical seeds and synthetic inputs (fp32: 1e-4 relative; bf16: loose bound), plus
+loss / metric / optimizer / sliding-window parity and the fused trainer."""
+import math
+
+import pytest
+import torch
+
+import oracle
+import unet_amd
+from helpers import rel_err, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def disks(nb, sp, seed, with_two=False):
+    g = torch.Generator().manual_seed(seed)
+    grids = torch.meshgrid(*[torch.arange(s, dtype=torch.float32) for s in sp], indexing="ij")
+    out = torch.zeros(nb, 1, *sp)
+    for b in range(nb):
+        c = [(0.3 + 0.4 * torch.rand(1, generator=g).item()) * s for s in sp]
+        r = (0.1 + 0.2 * torch.rand(1, generator=g).item()) * min(sp)
+        d2 = sum((gr - ci) ** 2 for gr, ci in zip(grids, c))
+        out[b, 0] = (d2 < r * r).float()
+        if with_two:
+            out[b, 0][d2 < (0.4 * r) ** 2] = 2.0
+    return out
+
+
+def make_pair(dims, channels, res_units, dropout, dtype, dev, seed=0):
+    torch.manual_seed(seed)
+    strides = (2,) * (len(channels) - 1)
+    o = oracle.UNet(dims, 1, 1, channels, strides, num_res_units=res_units, dropout=dropout)
+    # move the parameters away from their symmetric initial point (PReLU slopes, biases)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for n, p in o.named_parameters():
+            if n.endswith("adn.A.weight"):
+                p.copy_(0.1 + 0.3 * torch.rand(1, generator=g))
+    m = unet_amd.UNet(dims, 1, 1, channels, strides, num_res_units=res_units, dropout=dropout, compute_dtype=dtype)
+    m.load_state_dict(o.state_dict())
+    return o, m.to(dev)
+
+
+def run_both(o, m, x, t, dev, lambda_ce=1.0):
+    lo = oracle.DiceCELoss(sigmoid=True, lambda_ce=lambda_ce)
+    lm = unet_amd.DiceCELoss(sigmoid=True, lambda_ce=lambda_ce)
+    o.zero_grad()
+    yo = o(x)
+    loss_o = lo(yo, t)
+    loss_o.backward()
+    m.zero_grad()
+    ym = m(x.to(dev))
+    loss_m = lm(ym, t.to(dev))
+    loss_m.backward()
+    torch.cuda.synchronize()
+    return yo.detach(), loss_o.detach(), ym.detach().cpu(), loss_m.detach().cpu()
+
+
+CONFIGS = [
+    # dims, channels, res_units, batch, spatial
+    (2, (16, 32), 2, 2, (32, 32)),
+    (2, (16, 32, 64), 2, 2, (32, 48)),
+    (2, (16, 32, 64), 1, 1, (16, 16)),
+    (2, (16, 32, 64, 128, 256), 2, 2, (64, 64)),
+    (2, (32, 64, 128, 256, 512), 2, 1, (32, 32)),
+    (3, (16, 32), 2, 1, (16, 16, 16)),
+    (3, (16, 32, 64, 128, 256), 2, 1, (32, 32, 32)),
+    (2, (32, 32), 2, 1, (16, 16)),
+]
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: "%dd_%s_r%d_b%d_%s" % (c[0], "-".join(map(str, c[1])), c[2], c[3], "x".join(map(str, c[4]))))
+def test_fp32_logits_loss_and_gradients_match_oracle(dev, cfg):
+    dims, channels, ru, nb, sp = cfg
+    o, m = make_pair(dims, channels, ru, 0.0, torch.float32, dev)
+    o.train(); m.train()
+    g = torch.Generator().manual_seed(1234)
+    x = torch.rand(nb, 1, *sp, generator=g)
+    t = disks(nb, sp, 77)
+    yo, lo, ym, lm = run_both(o, m, x, t, dev)
+    assert rel_err(ym, yo) < 1e-4, "logits"
+    assert abs(float(lm) - float(lo)) < 1e-5 * max(1.0, abs(float(lo))), "loss"
+    gnorm = math.sqrt(sum(float(p.grad.double().pow(2).sum()) for p in o.parameters()))
+    bad = []
+    for (n, po), pm in zip(o.named_parameters(), m.parameters()):
+        go, gm = po.grad, pm.grad.cpu()
+        # relative to the tensor's own scale; tensors whose true gradient is rounding noise (biases in front
+        # of an instance norm) are held to the global gradient scale instead
+        scale = max(float(go.abs().max()), 1e-6 * gnorm)
+        err = float((gm - go).abs().max()) / scale
+        if err > 1e-4 * (5 if n.endswith("bias") else 1) and float((gm - go).abs().max()) > 2e-6 * gnorm:
+            bad.append((n, err))
+    assert not bad, bad[:5]
+
+
+@pytest.mark.parametrize("cfg", [CONFIGS[1], CONFIGS[3], CONFIGS[6]], ids=["2d_small", "2d_16-256", "3d_16-256"])
+def test_bf16_close_to_oracle(dev, cfg):
+    dims, channels, ru, nb, sp = cfg
+    o, m = make_pair(dims, channels, ru, 0.0, torch.bfloat16, dev)
+    o.train(); m.train()
+    g = torch.Generator().manual_seed(1234)
+    x = torch.rand(nb, 1, *sp, generator=g)
+    t = disks(nb, sp, 77)
+    yo, lo, ym, lm = run_both(o, m, x, t, dev)
+    assert rel_l2(ym, yo) < 3e-2, "logits"
+    assert abs(float(lm) - float(lo)) < 2e-2, "loss"
+    go = torch.cat([p.grad.flatten() for p in o.parameters()])
+    gm = torch.cat([p.grad.flatten().cpu() for p in m.parameters()])
+    assert rel_l2(gm, go) < 8e-2, "gradients"
+
+
+def test_eval_mode_and_no_grad_forward(dev):
+    o, m = make_pair(2, (16, 32, 64), 2, 0.1, torch.float32, dev)
+    o.eval(); m.eval()
+    x = torch.rand(3, 1, 32, 32, generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        yo = o(x)
+        ym = m(x.to(dev)).cpu()
+    assert rel_err(ym, yo) < 1e-4
+    # train mode with dropout: outputs differ from eval, stay finite, and are reproducible for one seed
+    m.train()
+    m.seed_dropout(11)
+    with torch.no_grad():
+        a = m(x.to(dev)).cpu()
+    m.seed_dropout(11)
+    with torch.no_grad():
+        b = m(x.to(dev)).cpu()
+    assert torch.equal(a, b) and torch.isfinite(a).all() and not torch.allclose(a, ym)
+
+
+def test_loss_closed_forms_and_label_dtypes(dev):
+    L = unet_amd.DiceCELoss(to_onehot_y=False, sigmoid=True)
+    n = 256
+    t1 = torch.ones(1, 1, n, n, device=dev)
+    assert abs(float(L(torch.zeros(1, 1, n, n, device=dev), t1)) - 1.0264806747) < 2e-6
+    t0 = torch.zeros(1, 1, n, n, device=dev)
+    assert abs(float(L(torch.full((1, 1, n, n), -20.0, device=dev), t0)) - 0.9310724139) < 2e-5
+    assert float(L(20 * (2 * t1 - 1), t1)) < 1e-7
+    # random case vs oracle, all label dtypes, label folding
+    g = torch.Generator().manual_seed(0)
+    z = torch.randn(4, 1, 40, 56, generator=g) * 3
+    t = disks(4, (40, 56), 5, with_two=True)
+    t_fold = t.clone(); t_fold[t_fold == 2] = 1
+    ref = oracle.DiceCELoss(sigmoid=True)
+    zr = z.clone().requires_grad_(True)
+    lr = ref(zr, t_fold); lr.backward()
+    for dt in (torch.float32, torch.int64, torch.uint8, torch.int32):
+        zg = z.clone().to(dev).requires_grad_(True)
+        lg = unet_amd.DiceCELoss(sigmoid=True, fold_label_two=True)(zg, t.to(dt).to(dev))
+        lg.backward()
+        assert abs(float(lg) - float(lr)) < 2e-6
+        assert rel_err(zg.grad.cpu(), zr.grad) < 2e-5
+    # plain Dice loss (lambda_ce = 0)
+    ld = unet_amd.DiceLoss(sigmoid=True)(z.to(dev), t_fold.to(dev))
+    assert abs(float(ld) - float(oracle.DiceLoss(sigmoid=True)(z, t_fold))) < 2e-6
+    # in-place fold of the reference loop
+    lab = t.clone().to(dev)
+    from unet_amd import _lib
+    _lib.check(_lib.load().mi_fold_labels(lab.data_ptr(), 0, lab.numel(), _lib.current_stream(dev)))
+    assert torch.equal(lab.cpu(), t_fold)
+
+
+def test_dice_metric_and_confusion_counts(dev):
+    g = torch.Generator().manual_seed(1)
+    pred = (torch.rand(6, 1, 48, 48, generator=g) > 0.6).float()
+    gt = disks(6, (48, 48), 9)
+    gt[2] = 0  # empty ground truth -> NaN, skipped by aggregate
+    mo, mm = oracle.DiceMetric(include_background=False, reduction="mean"), unet_amd.DiceMetric(include_background=False, reduction="mean")
+    ro = mo(y_pred=[p for p in pred], y=gt.long())
+    rm = mm(y_pred=[p.to(dev) for p in pred], y=gt.long().to(dev))
+    assert torch.allclose(rm.cpu(), ro, equal_nan=True, atol=1e-6)
+    mo(y_pred=pred[:2], y=gt[:2]); mm(y_pred=pred[:2].to(dev), y=gt[:2].to(dev))
+    assert abs(float(mm.aggregate()) - float(mo.aggregate())) < 1e-6
+    mm.reset()
+    assert mm.get_buffer() is None
+    # closed forms
+    a = torch.zeros(1, 1, 8, 8); a[..., :4] = 1
+    b = torch.zeros(1, 1, 8, 8); b[..., 2:6] = 1
+    for p, q, want in [(a, a, 1.0), (a, 1 - a, 0.0), (a, b, 0.5)]:
+        mm.reset(); mm(y_pred=p.to(dev), y=q.to(dev))
+        assert abs(float(mm.aggregate()) - want) < 1e-7
+    d, se, sp_ = unet_amd.calculate_dice_score(pred.to(dev), gt.to(dev))
+    do, seo, spo = oracle.calculate_dice_score(pred, gt)
+    assert abs(float(d) - float(do)) < 1e-6 and abs(float(se) - float(seo)) < 1e-6 and abs(float(sp_) - float(spo)) < 1e-6
+    # logits thresholded inside the kernel == sigmoid + AsDiscrete(0.5)
+    z = torch.randn(3, 1, 16, 16, generator=g)
+    post = unet_amd.Compose([unet_amd.Activations(sigmoid=True), unet_amd.AsDiscrete(threshold=0.5)])
+    c1 = unet_amd.confusion_counts(post(z.to(dev)), gt[:3, :, :16, :16].to(dev))
+    c2 = unet_amd.confusion_counts(z.to(dev), gt[:3, :, :16, :16].to(dev), binary=False, threshold=0.0)
+    assert torch.equal(c1, c2)
+
+
+def test_sliding_window_matches_oracle(dev):
+    g = torch.Generator().manual_seed(4)
+    pred_o = lambda w: w * 2.0 + 1.0
+    for shape, roi in [((2, 1, 96, 80), (64, 64)), ((1, 1, 40, 40), (64, 48)), ((3, 1, 64, 64), (64, 64)),
+                       ((1, 1, 40, 36, 44), (32, 32, 32))]:
+        x = torch.rand(*shape, generator=g)
+        ref = oracle.sliding_window_inference(x, roi, 4, pred_o)
+        out = unet_amd.sliding_window_inference(x.to(dev), roi, 4, pred_o)
+        assert out.shape == ref.shape
+        assert torch.allclose(out.cpu(), ref, atol=1e-6)
+    # with the network as predictor
+    o, m = make_pair(2, (16, 32, 64), 2, 0.0, torch.float32, dev)
+    o.eval(); m.eval()
+    x = torch.rand(2, 1, 80, 80, generator=g)
+    with torch.no_grad():
+        ref = oracle.sliding_window_inference(x, (48, 48), 4, o)
+        out = unet_amd.sliding_window_inference(x.to(dev), (48, 48), 4, m)
+    assert rel_err(out.cpu(), ref) < 1e-4
+
+
+def test_fused_adamw_matches_torch(dev):
+    o, m = make_pair(2, (16, 32, 64), 2, 0.0, torch.float32, dev)
+    opt_o = torch.optim.AdamW(o.parameters(), lr=5e-4)
+    opt_m = unet_amd.AdamW(m.parameters(), lr=5e-4, model=m)
+    sched_o = torch.optim.lr_scheduler.StepLR(opt_o, step_size=2, gamma=0.5)
+    sched_m = torch.optim.lr_scheduler.StepLR(opt_m, step_size=2, gamma=0.5)
+    g = torch.Generator().manual_seed(8)
+    for step in range(4):
+        for po, pm in zip(o.parameters(), m.parameters()):
+            gr = torch.randn(po.shape, generator=g)
+            po.grad = gr.clone(); pm.grad = gr.to(dev)
+        opt_o.step(); opt_m.step(); sched_o.step(); sched_m.step()
+    for (n, po), pm in zip(o.named_parameters(), m.parameters()):
+        assert torch.allclose(pm.detach().cpu(), po.detach(), rtol=2e-5, atol=2e-7), n
+    assert opt_m.param_groups[0]["lr"] == opt_o.param_groups[0]["lr"]
+
+
+def test_training_converges_like_oracle(dev, tmp_path):
+    """A fixed number of steps on the same synthetic task: the fused trainer (bf16 and fp32), the
+    autograd path + torch AdamW and the CPU oracle end with Dice within 0.005 of one another; the
+    checkpoint written by the product loads into the oracle."""
+    channels, sp, nb, steps = (16, 32, 64), (64, 64), 8, 60
+    g = torch.Generator().manual_seed(21)
+    xs = [torch.rand(nb, 1, *sp, generator=g) * 0.2 for _ in range(4)]
+    ts = [disks(nb, sp, 100 + i, with_two=True) for i in range(4)]
+    for x, t in zip(xs, ts):
+        x += (t > 0).float() * 0.6  # the organ is brighter than the background
+    def fold(t):
+        t = t.clone(); t[t == 2] = 1; return t
+    xv, tv = xs[0], fold(ts[0])
+
+    def dice_of(model, on_gpu):
+        model.eval()
+        with torch.no_grad():
+            z = model(xv.to(dev) if on_gpu else xv)
+        model.train()
+        met = (unet_amd if on_gpu else oracle).DiceMetric(include_background=False)
+        met(y_pred=(z >= 0).float(), y=(tv.to(dev) if on_gpu else tv))
+        return float(met.aggregate())
+
+    o, _ = make_pair(2, channels, 2, 0.0, torch.float32, dev, seed=5)
+    sd0 = {k: v.clone() for k, v in o.state_dict().items()}
+    opt = torch.optim.AdamW(o.parameters(), lr=2e-3)
+    lo = oracle.DiceCELoss(sigmoid=True)
+    o.train()
+    for i in range(steps):
+        opt.zero_grad(); lo(o(xs[i % 4]), fold(ts[i % 4])).backward(); opt.step()
+    d_ref = dice_of(o, False)
+    assert d_ref > 0.9
+
+    results = {}
+    for name, dt in [("fp32", torch.float32), ("bf16", torch.bfloat16)]:
+        m = unet_amd.UNet(2, 1, 1, channels, (2, 2), num_res_units=2, compute_dtype=dt)
+        m.load_state_dict(sd0); m.to(dev).train()
+        tr = unet_amd.Trainer(m, unet_amd.DiceCELoss(sigmoid=True, fold_label_two=True), unet_amd.AdamW(m.parameters(), lr=2e-3, model=m))
+        for i in range(steps):
+            tr.step(xs[i % 4].to(dev), ts[i % 4].to(dev))
+        assert math.isfinite(tr.loss_sum())
+        results[name] = dice_of(m, True)
+        if name == "bf16":
+            path = unet_amd.save_checkpoint(m, str(tmp_path / "liver_best_metric_model.pth"))
+            o2 = oracle.UNet(2, 1, 1, channels, (2, 2), num_res_units=2)
+            o2.load_state_dict(torch.load(path, weights_only=True))
+            assert abs(dice_of(o2, False) - results["bf16"]) < 0.005
+    m = unet_amd.UNet(2, 1, 1, channels, (2, 2), num_res_units=2, compute_dtype=torch.float32)
+    m.load_state_dict(sd0); m.to(dev).train()
+    opt = torch.optim.AdamW(m.parameters(), lr=2e-3)
+    lm = unet_amd.DiceCELoss(sigmoid=True)
+    for i in range(steps):
+        opt.zero_grad(); lm(m(xs[i % 4].to(dev)), fold(ts[i % 4]).to(dev)).backward(); opt.step()
+    results["autograd"] = dice_of(m, True)
+    for k, v in results.items():
+        assert abs(v - d_ref) < 0.005, (k, v, d_ref)

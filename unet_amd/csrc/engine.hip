@@ -1,0 +1,1142 @@
+// Network-level engine: turns a MONAI-style residual U-Net configuration into a fixed list
+// of kernel launches (forward and backward), owns the workspace layout and runs the lists on
+// a HIP stream.  Pure host logic plus launches; no device allocation, no synchronisation.
+//
+// Data layout decisions (all in the caller-provided workspace):
+//  * hidden activations are channels-last in the compute dtype; skip concatenation is free:
+//    the encoder output and the decoder output of a level are written side by side into
+//    one buffer whose pitch is the concatenated channel count;
+//  * the stride-2 encoder convolution and its stride-2 residual convolution share one
+//    launch (2*C output channels, same input tile);
+//  * convolutions that feed an instance norm skip their bias (it cancels exactly) and emit
+//    the per-(image, channel) sums the norm needs from their epilogue;
+//  * weight gradients are accumulated per workgroup, written as slabs and reduced in a
+//    fixed order (deterministic), one reduction launch per gradient bucket.
+#include <math.h>
+#include <stdio.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "common.h"
+#include "geom.h"
+#include "kparams.h"
+#include "lossparams.h"
+#include "../../include/unet_mi355.h"
+
+static thread_local std::string g_err;
+void mi_set_error(const std::string& s) { g_err = s; }
+extern "C" const char* mi_last_error(void) { return g_err.c_str(); }
+extern "C" int mi_version(void) { return 100; }
+
+namespace {
+
+enum StepKind {
+    K_IGEMM, K_WGRAD, K_NORM_FWD, K_NORM_BWD, K_C1_FWD, K_C1_T, K_C1_WGRAD, K_STENCIL, K_STENCIL_WGRAD, K_ADD,
+    K_MEMSET, K_REDUCE, K_PACK
+};
+enum Base { B_ARENA, B_PARAMS, B_GRADS, B_XIN, B_LOGITS, B_DLOGITS, B_NBASE };
+
+struct Reloc { size_t field_off; int base; };
+
+struct AddArgs { char* dst; int dpitch, dcoff; const char* src; int spitch, scoff, c; long long npix; };
+struct MemsetArgs { char* ptr; size_t bytes; };
+struct TabArgs { int first, count, max_elems; };
+
+struct Step {
+    int kind = 0, dtype = 0, bucket = 0;
+    double work = 0; int work_is_flops = 0;
+    std::string layer, kernel;
+    IgemmParams ig; WgradParams wg; NormParams nm; C1Params c1; StencilParams stn;
+    AddArgs add; MemsetArgs ms; TabArgs tab;
+    std::vector<Reloc> rel;
+    double total_ms = 0; long long launches = 0;
+    Step() {
+        memset(&ig, 0, sizeof(ig)); memset(&wg, 0, sizeof(wg)); memset(&nm, 0, sizeof(nm));
+        memset(&c1, 0, sizeof(c1)); memset(&stn, 0, sizeof(stn)); memset(&add, 0, sizeof(add));
+        memset(&ms, 0, sizeof(ms)); memset(&tab, 0, sizeof(tab));
+    }
+};
+
+#define REL(step, ps, field, base, off)                                                               \
+    do {                                                                                              \
+        (ps).field = (decltype((ps).field))(uintptr_t)(off);                                          \
+        (step).rel.push_back(Reloc{offsetof(std::remove_reference<decltype(ps)>::type, field), base}); \
+    } while (0)
+
+template <class P>
+P resolve(const Step& s, const P& src, char* const* bases) {
+    P q = src;
+    for (const Reloc& r : s.rel) {
+        char** f = reinterpret_cast<char**>(reinterpret_cast<char*>(&q) + r.field_off);
+        *f = bases[r.base] + reinterpret_cast<uintptr_t>(*f);
+    }
+    return q;
+}
+
+struct Ten {  // a channels-last tensor inside the arena
+    size_t off = 0; int pitch = 0; int coff = 0; int base = B_ARENA;
+};
+
+struct ParamRec {
+    std::string name; int ndim; int shape[5]; long long numel; long long offset; int bucket;
+};
+
+struct ProfEvent { hipEvent_t a, b; int backward, step; };
+
+}  // namespace
+
+struct mi_unet {
+    mi_unet_cfg cfg;
+    int L, R, nd, dt, esz, nb;
+    int KK;  // taps of a 3^nd kernel
+    std::vector<ParamRec> params;
+    std::map<std::string, int> pindex;
+    long long nfloats = 0;
+    long long bucket_off[3], bucket_cnt[3];
+    std::vector<Step> fwd, bwd;
+    size_t arena = 0;
+    // descriptor tables (pointer fields hold offsets until resolved)
+    std::vector<PackDesc> packs; std::vector<int> pack_is_bwd;
+    std::vector<ReduceDesc> reduces; std::vector<int> reduce_has_b;
+    std::vector<PackDesc> packs_res; std::vector<ReduceDesc> reduces_res;
+    size_t off_pack_tab = 0, off_reduce_tab = 0;
+    size_t off_stats = 0, stats_bytes = 0, off_bstats = 0, bstats_bytes = 0;
+    char* cached_pack_bases[2] = {nullptr, nullptr};
+    char* cached_reduce_bases[2] = {nullptr, nullptr};
+    double flops_fwd = 0, flops_bwd = 0;
+    int n_fwd_packs = 0;
+    // profiling
+    bool prof = false;
+    std::vector<ProfEvent> events;
+    int rd[9][3]; long long rp[9];
+};
+
+namespace {
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Builder {
+    mi_unet& u;
+    explicit Builder(mi_unet& uu) : u(uu) {}
+    int layer_id = 0;
+    int cur_bucket = 0;
+
+    size_t alloc(size_t bytes) {
+        size_t o = u.arena;
+        u.arena = align_up(u.arena + bytes, 256);
+        return o;
+    }
+    Ten new_tensor(int res, int pitch, int esz) {
+        Ten t; t.off = alloc((size_t)u.nb * u.rp[res] * pitch * esz); t.pitch = pitch; t.coff = 0; return t;
+    }
+    long long poff(const std::string& name) { return u.params[u.pindex.at(name)].offset; }
+
+    ConvShape shape(int transposed, int ksize, int stride, int cin, int cout, int res_in) {
+        ConvShape s; s.ndim = u.nd; s.transposed = transposed; s.ksize = ksize; s.stride = stride;
+        s.cin = cin; s.cout = cout; s.nb = u.nb;
+        for (int d = 0; d < 3; ++d) s.in_dims[d] = u.rd[res_in][d];
+        return s;
+    }
+
+    // ---- packed weights -----------------------------------------------------------------------
+    // returns arena offset of the packed tensor [ntaps][Ntot][Ktot]
+    size_t packed_alloc(int ntaps, int Ntot, int Ktot) { return alloc((size_t)ntaps * Ntot * Ktot * u.esz); }
+    void add_pack(bool bwd, size_t dst_off, const std::string& wname, int N, int K, int ntaps, const int* kidx,
+                  int sn, int sk, int Ntot, int Ktot, int n_off, int k_off) {
+        PackDesc d; memset(&d, 0, sizeof(d));
+        d.src = (const float*)(uintptr_t)(poff(wname) * sizeof(float));
+        d.dst = (void*)(uintptr_t)dst_off;
+        d.N = N; d.K = K; d.ntaps = ntaps; d.sn = sn; d.sk = sk; d.Ntot = Ntot; d.Ktot = Ktot;
+        d.n_off = n_off; d.k_off = k_off;
+        for (int i = 0; i < ntaps; ++i) d.kidx[i] = kidx[i];
+        u.packs.push_back(d); u.pack_is_bwd.push_back(bwd ? 1 : 0);
+    }
+
+    // ---- reductions ----------------------------------------------------------------------------
+    void add_reduce(size_t partial_off, size_t pbias_off, int nslab, int ntaps, int Ftot, int S, int f_off, int Fcnt,
+                    int KKdst, const int* kidx, const std::string& wname, const std::string& bname) {
+        ReduceDesc d; memset(&d, 0, sizeof(d));
+        d.partial = (const float*)(uintptr_t)partial_off; d.partial_bias = (const float*)(uintptr_t)pbias_off;
+        d.nslab = nslab; d.ntaps = ntaps; d.Ftot = Ftot; d.S = S; d.f_off = f_off; d.Fcnt = Fcnt; d.KK = KKdst;
+        for (int i = 0; i < ntaps; ++i) d.kidx[i] = kidx ? kidx[i] : i;
+        d.dst_w = (float*)(uintptr_t)(poff(wname) * sizeof(float));
+        int hasb = 0;
+        if (!bname.empty()) { d.dst_b = (float*)(uintptr_t)(poff(bname) * sizeof(float)); hasb = 1; }
+        u.reduces.push_back(d); u.reduce_has_b.push_back(hasb);
+        bucket_of_reduce.push_back(cur_bucket);
+    }
+    // scalar copy (PReLU slope gradient) or zero fill (nslab = 0)
+    void add_scalar_reduce(size_t src_off, int nslab, const std::string& name, int count = 1) {
+        ReduceDesc d; memset(&d, 0, sizeof(d));
+        d.partial = (const float*)(uintptr_t)src_off; d.partial_bias = nullptr;
+        d.nslab = nslab; d.ntaps = 1; d.Ftot = count; d.S = 1; d.f_off = 0; d.Fcnt = count; d.KK = 1; d.kidx[0] = 0;
+        d.dst_w = (float*)(uintptr_t)(poff(name) * sizeof(float));
+        u.reduces.push_back(d); u.reduce_has_b.push_back(0);
+        bucket_of_reduce.push_back(cur_bucket);
+    }
+    std::vector<int> bucket_of_reduce;
+
+    // ---- steps ---------------------------------------------------------------------------------
+    Step& push(std::vector<Step>& list, int kind, const std::string& layer) {
+        list.emplace_back();
+        Step& s = list.back();
+        s.kind = kind; s.dtype = u.dt; s.bucket = cur_bucket; s.layer = layer;
+        return s;
+    }
+
+    // generic igemm step. in1 optional (c_in0 < K). stats_off = (size_t)-1: none.
+    bool add_igemm(std::vector<Step>& list, const std::string& layer, const ConvShape& cs, int dir, const Ten& in0,
+                   int in0_c, const Ten* in1, int K, int N, size_t w_off, const char* bias_name, int bias_c0,
+                   const Ten& out, const Ten* addend, size_t stats_off, int stats_c, int nstat, int kidx_out[MI_MAX_TAPS],
+                   int* ntaps_out) {
+        Step& s = push(list, K_IGEMM, layer);
+        IgemmParams& p = s.ig;
+        if (!igemm_geometry(cs, dir, p, kidx_out, ntaps_out)) { mi_set_error("igemm geometry: odd size under stride 2"); return false; }
+        REL(s, p, in0, in0.base, in0.off);
+        p.in0_pitch = in0.pitch; p.in0_coff = in0.coff; p.in0_c = in0_c;
+        if (in1) { REL(s, p, in1, in1->base, in1->off); p.in1_pitch = in1->pitch; p.in1_coff = in1->coff; }
+        p.K = K; p.N = N;
+        REL(s, p, w, B_ARENA, w_off);
+        if (bias_name) { REL(s, p, bias, B_PARAMS, poff(bias_name) * sizeof(float)); p.bias_c0 = bias_c0; }
+        REL(s, p, out, out.base, out.off); p.out_pitch = out.pitch; p.out_coff = out.coff;
+        if (addend) { REL(s, p, addend, addend->base, addend->off); p.add_pitch = addend->pitch; p.add_coff = addend->coff; }
+        if (stats_off != (size_t)-1) { REL(s, p, stats, B_ARENA, stats_off); p.stats_c = stats_c; p.nstat = nstat; }
+        int cps, nfrag;
+        igemm_config(u.dt, p, &cps, &nfrag);
+        char kb[96];
+        snprintf(kb, sizeof(kb), "igemm_kernel<%s,%d,%d>", u.dt ? "BF16" : "F32", cps, nfrag);
+        s.kernel = kb;
+        double bpix = (double)p.bd[0] * p.bd[1] * p.bd[2] * u.nb;
+        s.work = 2.0 * bpix * (double)(*ntaps_out) * K * N; s.work_is_flops = 1;
+        if (&list == &u.fwd) u.flops_fwd += s.work; else u.flops_bwd += s.work;
+        return true;
+    }
+
+    // weight-gradient step; returns slab offsets through the reduce descriptors the caller adds
+    void add_wgrad(const std::string& layer, const ConvShape& cs, const Ten& f0, int f0_c, const Ten* f1, int F,
+                   const Ten& sten, int S, size_t* partial_off, size_t* pbias_off, int* nslab, int* ntaps) {
+        Step& s = push(u.bwd, K_WGRAD, layer);
+        WgradParams& p = s.wg;
+        wgrad_geometry(cs, p);
+        p.F = F; p.S = S; p.f0_c = f0_c;
+        REL(s, p, f0, f0.base, f0.off); p.f0_pitch = f0.pitch; p.f0_coff = f0.coff;
+        if (f1) { REL(s, p, f1, f1->base, f1->off); p.f1_pitch = f1->pitch; p.f1_coff = f1->coff; }
+        REL(s, p, s, sten.base, sten.off); p.s_pitch = sten.pitch; p.s_coff = sten.coff;
+        int ff, sf, wf, wsn;
+        p.nsplit = 1;
+        wgrad_config(u.dt, p, &ff, &sf, &wf, &wsn);
+        const int blocks = (F / (16 * ff * wf)) * (S / (16 * sf * wsn)) * p.ntapg;
+        int nsplit = (256 + blocks - 1) / blocks;
+        if (nsplit > p.tiles_total) nsplit = p.tiles_total;
+        if (nsplit < 1) nsplit = 1;
+        p.nsplit = nsplit;
+        const int slabs = wgrad_slabs(u.dt, p);
+        const size_t po = alloc((size_t)slabs * p.ntaps_total * F * S * sizeof(float));
+        const size_t pb = alloc((size_t)slabs * F * sizeof(float));
+        REL(s, p, partial, B_ARENA, po);
+        REL(s, p, partial_bias, B_ARENA, pb);
+        *partial_off = po; *pbias_off = pb; *nslab = slabs; *ntaps = p.ntaps_total;
+        char kb[96];
+        snprintf(kb, sizeof(kb), "wgrad_kernel<%s,%d,%d,%d,%d,%d>", u.dt ? "BF16" : "F32", p.ntaps_total / p.ntapg, ff, sf, wf, wsn);
+        s.kernel = kb;
+        double bpix = (double)p.bd[0] * p.bd[1] * p.bd[2] * u.nb;
+        s.work = 2.0 * bpix * p.ntaps_total * (double)F * S; s.work_is_flops = 1;
+        u.flops_bwd += s.work;
+    }
+
+    void add_norm_fwd(const std::string& layer, int res, int c, int dt, const Ten& raw, size_t stats_off,
+                      const std::string& alpha, const Ten* resid, const Ten& out, int lid) {
+        Step& s = push(u.fwd, K_NORM_FWD, layer);
+        s.dtype = dt;
+        NormParams& p = s.nm;
+        REL(s, p, x, raw.base, raw.off); p.x_pitch = raw.pitch; p.x_coff = raw.coff;
+        if (resid) { REL(s, p, res, resid->base, resid->off); p.res_pitch = resid->pitch; p.res_coff = resid->coff; }
+        REL(s, p, out, out.base, out.off); p.out_pitch = out.pitch; p.out_coff = out.coff;
+        REL(s, p, stats, B_ARENA, stats_off);
+        REL(s, p, alpha, B_PARAMS, poff(alpha) * sizeof(float));
+        p.nb = u.nb; p.npix = (int)u.rp[res]; p.c = c; p.eps = 1e-5f; p.layer = (unsigned)lid;
+        const int esz = dt ? 2 : 4;
+        s.kernel = c == 1 ? "norm1_fwd_kernel" : (dt ? "norm_fwd_kernel<BF16>" : "norm_fwd_kernel<F32>");
+        s.work = (double)u.nb * u.rp[res] * c * esz * (resid ? 3.0 : 2.0);
+    }
+
+    void add_norm_bwd(const std::string& layer, int res, int c, int dt, const Ten& dy, const Ten& raw, size_t stats_off,
+                      const std::string& alpha, const Ten& dx, int lid) {
+        Step& s = push(u.bwd, K_NORM_BWD, layer);
+        s.dtype = dt;
+        NormParams& p = s.nm;
+        REL(s, p, x, raw.base, raw.off); p.x_pitch = raw.pitch; p.x_coff = raw.coff;
+        REL(s, p, dy, dy.base, dy.off); p.dy_pitch = dy.pitch; p.dy_coff = dy.coff;
+        REL(s, p, out, dx.base, dx.off); p.out_pitch = dx.pitch; p.out_coff = dx.coff;
+        REL(s, p, stats, B_ARENA, stats_off);
+        const size_t bs = bstats_alloc((size_t)u.nb * MI_NSLOT * c * 2 * sizeof(float));
+        const size_t da = bstats_alloc(sizeof(float));
+        REL(s, p, bstats, B_ARENA, bs);
+        REL(s, p, dalpha, B_ARENA, da);
+        REL(s, p, alpha, B_PARAMS, poff(alpha) * sizeof(float));
+        p.nb = u.nb; p.npix = (int)u.rp[res]; p.c = c; p.eps = 1e-5f; p.layer = (unsigned)lid;
+        const int esz = dt ? 2 : 4;
+        s.kernel = c == 1 ? "norm1_bwd_kernels" : (dt ? "norm_bwd_kernels<BF16>" : "norm_bwd_kernels<F32>");
+        s.work = (double)u.nb * u.rp[res] * c * esz * 5.0;
+        add_scalar_reduce(da, 1, alpha);
+    }
+
+    // statistics regions are carved from two contiguous blocks so one memset clears each
+    size_t stats_cursor = 0, bstats_cursor = 0;
+    size_t stats_alloc(size_t bytes) { size_t o = u.off_stats + stats_cursor; stats_cursor = align_up(stats_cursor + bytes, 16); return o; }
+    size_t bstats_alloc(size_t bytes) { size_t o = u.off_bstats + bstats_cursor; bstats_cursor = align_up(bstats_cursor + bytes, 16); return o; }
+};
+
+// enumerate parameters in MONAI's registration (state_dict) order
+void enum_params(mi_unet& u) {
+    const int L = u.L, R = u.R, nd = u.nd;
+    const int* c = u.cfg.channels;
+    auto add = [&](const std::string& name, std::vector<int> shape, int bucket) {
+        ParamRec r; r.name = name; r.ndim = (int)shape.size(); r.numel = 1;
+        for (int i = 0; i < 5; ++i) r.shape[i] = i < (int)shape.size() ? shape[i] : 1;
+        for (int v : shape) r.numel *= v;
+        r.offset = -1; r.bucket = bucket;
+        u.pindex[name] = (int)u.params.size();
+        u.params.push_back(r);
+    };
+    auto wshape = [&](int a, int b, int k) {
+        std::vector<int> s = {a, b};
+        for (int i = 0; i < nd; ++i) s.push_back(k);
+        return s;
+    };
+    // recursive blocks
+    struct Rec {
+        static void block(mi_unet& u, const std::string& P, int l, decltype(add)& add, decltype(wshape)& wshape) {
+            const int L = u.L, R = u.R; const int* c = u.cfg.channels;
+            const int cin = l == 0 ? u.cfg.in_channels : c[l - 1];
+            const int cout = c[l];
+            // down residual unit at P.0 (stride 2)
+            res_unit(u, P + ".0", cin, cout, 3, R, false, 2, add, wshape);
+            if (l < L - 2) block(u, P + ".1.submodule", l + 1, add, wshape);
+            else res_unit(u, P + ".1.submodule", c[L - 2], c[L - 1], (c[L - 2] != c[L - 1]) ? 1 : 0, R, false, 1, add, wshape);
+            // up layer at P.2
+            const int upc = (l < L - 2) ? 2 * cout : c[L - 2] + c[L - 1];
+            const int outc = l == 0 ? u.cfg.out_channels : c[l - 1];
+            const int bk = 0;
+            add(P + ".2.0.conv.weight", wshape(upc, outc, 3), bk);
+            add(P + ".2.0.conv.bias", {outc}, bk);
+            add(P + ".2.0.adn.A.weight", {1}, bk);
+            add(P + ".2.1.conv.unit0.conv.weight", wshape(outc, outc, 3), bk);
+            add(P + ".2.1.conv.unit0.conv.bias", {outc}, bk);
+            if (l != 0) add(P + ".2.1.conv.unit0.adn.A.weight", {1}, bk);
+        }
+        // rk: residual kernel size (0 = identity)
+        static void res_unit(mi_unet& u, const std::string& P, int cin, int cout, int rk, int R, bool, int bucket,
+                             decltype(add)& add, decltype(wshape)& wshape) {
+            for (int su = 0; su < R; ++su) {
+                const std::string q = P + ".conv.unit" + std::to_string(su);
+                add(q + ".conv.weight", wshape(cout, su == 0 ? cin : cout, 3), bucket);
+                add(q + ".conv.bias", {cout}, bucket);
+                add(q + ".adn.A.weight", {1}, bucket);
+            }
+            if (rk) {
+                add(P + ".residual.weight", wshape(cout, cin, rk), bucket);
+                add(P + ".residual.bias", {cout}, bucket);
+            }
+        }
+    };
+    Rec::block(u, "model", 0, add, wshape);
+    (void)L; (void)R; (void)c;
+    // offsets in backward-completion (bucket) order, 16-byte aligned
+    long long off = 0;
+    for (int b = 0; b < 3; ++b) {
+        u.bucket_off[b] = off;
+        // within the decoder bucket the top layer finishes first; order by level for buckets 0 and 2
+        std::vector<int> idx;
+        for (int i = 0; i < (int)u.params.size(); ++i) if (u.params[i].bucket == b) idx.push_back(i);
+        auto depth = [&](const std::string& n) { int d = 0; size_t p = 0; while ((p = n.find("submodule", p)) != std::string::npos) { ++d; p += 9; } return d; };
+        if (b == 0) std::stable_sort(idx.begin(), idx.end(), [&](int a, int bb) { return depth(u.params[a].name) < depth(u.params[bb].name); });
+        if (b == 2) std::stable_sort(idx.begin(), idx.end(), [&](int a, int bb) { return depth(u.params[a].name) > depth(u.params[bb].name); });
+        for (int i : idx) { u.params[i].offset = off; off += (u.params[i].numel + 3) / 4 * 4; }
+        u.bucket_cnt[b] = off - u.bucket_off[b];
+    }
+    u.nfloats = off;
+}
+
+bool build(mi_unet& u) {
+    Builder B(u);
+    const int L = u.L, R = u.R, nd = u.nd, dt = u.dt, esz = u.esz, nb = u.nb;
+    const int* c = u.cfg.channels;
+    const int KK = u.KK;
+    const bool train = u.cfg.with_backward != 0;
+    int nat[MI_MAX_TAPS];
+    for (int i = 0; i < MI_MAX_TAPS; ++i) nat[i] = i;
+
+    // statistics blocks: reserve generously (sum over all norms), exact use tracked by cursors
+    {
+        size_t tot = 0;
+        for (int l = 0; l < L; ++l) tot += (size_t)(3 * R + 4) * nb * MI_NSLOT * (size_t)c[l] * 2 * sizeof(float) + 4096;
+        u.off_stats = B.alloc(tot); u.stats_bytes = tot;
+        u.off_bstats = B.alloc(tot); u.bstats_bytes = tot;
+    }
+    std::vector<int> Pcat(L);
+    std::vector<Ten> cat(L), gcat(L);
+    for (int l = 0; l <= L - 2; ++l) {
+        Pcat[l] = (l < L - 2) ? 2 * c[l] : c[L - 2] + c[L - 1];
+        cat[l] = B.new_tensor(l + 1, Pcat[l], esz);
+        if (train) gcat[l] = B.new_tensor(l + 1, Pcat[l], esz);
+    }
+    Ten xin; xin.base = B_XIN; xin.off = 0; xin.pitch = 1; xin.coff = 0;
+    Ten logits; logits.base = B_LOGITS; logits.pitch = 1;
+    Ten dlogits; dlogits.base = B_DLOGITS; dlogits.pitch = 1;
+
+    struct UnitSave { Ten raw; size_t stats; Ten act; std::string alpha; int lid; size_t wfwd, wdg; std::string wname, bname; };
+    struct DownSave { Ten dnA; std::vector<UnitSave> un; size_t wf, wd; int ntaps_d; };
+    std::vector<DownSave> down(L - 1);
+    struct BotSave { std::vector<UnitSave> un; Ten res; bool has_res_conv; size_t wres_f, wres_d; } bot;
+    struct UpSave { Ten rawT, actT, rawU; size_t statsT, statsU; int lidT, lidU; size_t wT_f, wT_d, wU_f, wU_d; } ;
+    std::vector<UpSave> up(L - 1);
+
+    auto wkey = [&](const std::string& P) { return P + ".conv.weight"; };
+    std::vector<std::string> dprefix(L - 1), uprefix(L - 1);
+    std::string botprefix;
+    {
+        std::string P = "model";
+        for (int l = 0; l <= L - 2; ++l) {
+            dprefix[l] = P + ".0"; uprefix[l] = P + ".2";
+            if (l < L - 2) P = P + ".1.submodule"; else botprefix = P + ".1.submodule";
+        }
+    }
+    int kidx[MI_MAX_TAPS], ntaps = 0;
+
+    // ================= forward =================
+    B.cur_bucket = 0;
+    {
+        Step& s = B.push(u.fwd, K_MEMSET, "clear forward statistics");
+        REL(s, s.ms, ptr, B_ARENA, u.off_stats); s.ms.bytes = 0;  // bytes patched after the build
+        s.kernel = "hipMemsetAsync";
+        Step& p = B.push(u.fwd, K_PACK, "pack weights");
+        p.kernel = dt ? "pack_kernel<BF16>" : "pack_kernel<F32>";
+    }
+    for (int l = 0; l <= L - 2; ++l) {
+        const int cin = l == 0 ? 1 : c[l - 1], cout = c[l];
+        const std::string P = dprefix[l];
+        const std::string lname = "down" + std::to_string(l);
+        DownSave& D = down[l];
+        D.dnA = B.new_tensor(l + 1, 2 * cout, esz);
+        D.un.resize(R);
+        for (int su = 0; su < R; ++su) {
+            D.un[su].stats = B.stats_alloc((size_t)nb * MI_NSLOT * cout * 2 * sizeof(float));
+            D.un[su].alpha = P + ".conv.unit" + std::to_string(su) + ".adn.A.weight";
+            D.un[su].lid = B.layer_id++;
+            D.un[su].wname = P + ".conv.unit" + std::to_string(su) + ".conv.weight";
+            D.un[su].bname = P + ".conv.unit" + std::to_string(su) + ".conv.bias";
+        }
+        if (l == 0) {
+            Step& s = B.push(u.fwd, K_C1_FWD, lname + ".unit0+residual conv s2 (1->2C)");
+            C1Params& p = s.c1;
+            REL(s, p, x1, B_XIN, 0);
+            REL(s, p, y_out, B_ARENA, D.dnA.off); p.y_pitch = 2 * cout; p.y_coff = 0; p.N = 2 * cout;
+            REL(s, p, w, B_PARAMS, B.poff(D.un[0].wname) * sizeof(float));
+            REL(s, p, w2, B_PARAMS, B.poff(P + ".residual.weight") * sizeof(float)); p.n_w1 = cout;
+            REL(s, p, bias, B_PARAMS, B.poff(P + ".residual.bias") * sizeof(float)); p.bias_c0 = cout;
+            REL(s, p, stats, B_ARENA, D.un[0].stats); p.stats_c = cout; p.nstat = cout;
+            p.ndim = nd; p.nb = nb;
+            for (int d = 0; d < 3; ++d) { p.fd[d] = u.rd[0][d]; p.cd[d] = u.rd[1][d]; }
+            s.kernel = dt ? "c1_s2_fwd_kernel<BF16>" : "c1_s2_fwd_kernel<F32>";
+            s.work = (double)nb * (u.rp[0] * 4.0 + u.rp[1] * 2.0 * cout * esz);
+            u.flops_fwd += 2.0 * nb * u.rp[1] * KK * 2.0 * cout;
+        } else {
+            ConvShape cs = B.shape(0, 3, 2, cin, 2 * cout, l);
+            D.wf = B.packed_alloc(KK, 2 * cout, cin);
+            Ten in = cat[l - 1];
+            if (!B.add_igemm(u.fwd, lname + ".unit0+residual conv s2", cs, DIR_FWD, in, cin, nullptr, cin, 2 * cout, D.wf,
+                             (P + ".residual.bias").c_str(), cout, D.dnA, nullptr, D.un[0].stats, cout, cout, kidx, &ntaps))
+                return false;
+            B.add_pack(false, D.wf, D.un[0].wname, cout, cin, ntaps, kidx, cin * KK, KK, 2 * cout, cin, 0, 0);
+            B.add_pack(false, D.wf, P + ".residual.weight", cout, cin, ntaps, kidx, cin * KK, KK, 2 * cout, cin, cout, 0);
+        }
+        D.un[0].raw = D.dnA;  // channels [0, cout)
+        for (int su = 0; su < R; ++su) {
+            Ten res = D.dnA; res.coff = cout;
+            if (su < R - 1) {
+                D.un[su].act = B.new_tensor(l + 1, cout, esz);
+                B.add_norm_fwd(lname + ".unit" + std::to_string(su) + " norm+prelu", l + 1, cout, dt, D.un[su].raw,
+                               D.un[su].stats, D.un[su].alpha, nullptr, D.un[su].act, D.un[su].lid);
+                D.un[su + 1].raw = B.new_tensor(l + 1, cout, esz);
+                ConvShape cs = B.shape(0, 3, 1, cout, cout, l + 1);
+                D.un[su + 1].wfwd = B.packed_alloc(KK, cout, cout);
+                if (!B.add_igemm(u.fwd, lname + ".unit" + std::to_string(su + 1) + " conv", cs, DIR_FWD, D.un[su].act, cout,
+                                 nullptr, cout, cout, D.un[su + 1].wfwd, nullptr, 0, D.un[su + 1].raw, nullptr,
+                                 D.un[su + 1].stats, cout, cout, kidx, &ntaps))
+                    return false;
+                B.add_pack(false, D.un[su + 1].wfwd, D.un[su + 1].wname, cout, cout, ntaps, kidx, cout * KK, KK, cout, cout, 0, 0);
+            } else {
+                Ten out = cat[l]; out.coff = 0;
+                B.add_norm_fwd(lname + ".unit" + std::to_string(su) + " norm+prelu+residual", l + 1, cout, dt, D.un[su].raw,
+                               D.un[su].stats, D.un[su].alpha, &res, out, D.un[su].lid);
+            }
+        }
+    }
+    // ---- bottom ----
+    {
+        const int cin = c[L - 2], cout = c[L - 1], res = L - 1;
+        const std::string P = botprefix;
+        bot.un.resize(R);
+        bot.has_res_conv = cin != cout;
+        Ten in = cat[L - 2]; in.coff = 0;
+        for (int su = 0; su < R; ++su) {
+            UnitSave& U = bot.un[su];
+            U.stats = B.stats_alloc((size_t)nb * MI_NSLOT * cout * 2 * sizeof(float));
+            U.alpha = P + ".conv.unit" + std::to_string(su) + ".adn.A.weight";
+            U.wname = P + ".conv.unit" + std::to_string(su) + ".conv.weight";
+            U.bname = P + ".conv.unit" + std::to_string(su) + ".conv.bias";
+            U.lid = B.layer_id++;
+            U.raw = B.new_tensor(res, cout, esz);
+            const int ci = su == 0 ? cin : cout;
+            ConvShape cs = B.shape(0, 3, 1, ci, cout, res);
+            U.wfwd = B.packed_alloc(KK, cout, ci);
+            const Ten& src = su == 0 ? in : bot.un[su - 1].act;
+            if (!B.add_igemm(u.fwd, "bottom.unit" + std::to_string(su) + " conv", cs, DIR_FWD, src, ci, nullptr, ci, cout,
+                             U.wfwd, nullptr, 0, U.raw, nullptr, U.stats, cout, cout, kidx, &ntaps))
+                return false;
+            B.add_pack(false, U.wfwd, U.wname, cout, ci, ntaps, kidx, ci * KK, KK, cout, ci, 0, 0);
+            if (su == 0) {
+                if (bot.has_res_conv) {
+                    bot.res = B.new_tensor(res, cout, esz);
+                    ConvShape cr = B.shape(0, 1, 1, cin, cout, res);
+                    bot.wres_f = B.packed_alloc(1, cout, cin);
+                    if (!B.add_igemm(u.fwd, "bottom.residual conv 1x1", cr, DIR_FWD, in, cin, nullptr, cin, cout, bot.wres_f,
+                                     (P + ".residual.bias").c_str(), 0, bot.res, nullptr, (size_t)-1, 0, 0, kidx, &ntaps))
+                        return false;
+                    B.add_pack(false, bot.wres_f, P + ".residual.weight", cout, cin, ntaps, kidx, cin, 1, cout, cin, 0, 0);
+                } else {
+                    bot.res = in;
+                }
+            }
+            if (su < R - 1) {
+                U.act = B.new_tensor(res, cout, esz);
+                B.add_norm_fwd("bottom.unit" + std::to_string(su) + " norm+prelu", res, cout, dt, U.raw, U.stats, U.alpha,
+                               nullptr, U.act, U.lid);
+            } else {
+                Ten out = cat[L - 2]; out.coff = cin;
+                B.add_norm_fwd("bottom.unit" + std::to_string(su) + " norm+prelu+residual", res, cout, dt, U.raw, U.stats,
+                               U.alpha, &bot.res, out, U.lid);
+            }
+        }
+    }
+    // ---- up path ----
+    for (int l = L - 2; l >= 0; --l) {
+        const std::string P = uprefix[l];
+        const std::string lname = "up" + std::to_string(l);
+        UpSave& U = up[l];
+        const int K = Pcat[l];
+        const int outc = l > 0 ? c[l - 1] : 1;
+        U.lidT = B.layer_id++; U.lidU = B.layer_id++;
+        if (l > 0) {
+            U.rawT = B.new_tensor(l, outc, esz); U.actT = B.new_tensor(l, outc, esz); U.rawU = B.new_tensor(l, outc, esz);
+            U.statsT = B.stats_alloc((size_t)nb * MI_NSLOT * outc * 2 * sizeof(float));
+            U.statsU = B.stats_alloc((size_t)nb * MI_NSLOT * outc * 2 * sizeof(float));
+            ConvShape ct = B.shape(1, 3, 2, K, outc, l + 1);
+            U.wT_f = B.packed_alloc(KK, outc, K);
+            if (!B.add_igemm(u.fwd, lname + ".convT", ct, DIR_FWD, cat[l], K, nullptr, K, outc, U.wT_f, nullptr, 0, U.rawT,
+                             nullptr, U.statsT, outc, outc, kidx, &ntaps))
+                return false;
+            B.add_pack(false, U.wT_f, P + ".0.conv.weight", outc, K, ntaps, kidx, KK, outc * KK, outc, K, 0, 0);
+            B.add_norm_fwd(lname + ".convT norm+prelu", l, outc, dt, U.rawT, U.statsT, P + ".0.adn.A.weight", nullptr, U.actT, U.lidT);
+            ConvShape cu = B.shape(0, 3, 1, outc, outc, l);
+            U.wU_f = B.packed_alloc(KK, outc, outc);
+            if (!B.add_igemm(u.fwd, lname + ".ru conv", cu, DIR_FWD, U.actT, outc, nullptr, outc, outc, U.wU_f, nullptr, 0,
+                             U.rawU, nullptr, U.statsU, outc, outc, kidx, &ntaps))
+                return false;
+            B.add_pack(false, U.wU_f, P + ".1.conv.unit0.conv.weight", outc, outc, ntaps, kidx, outc * KK, KK, outc, outc, 0, 0);
+            Ten out = cat[l - 1]; out.coff = c[l - 1];
+            B.add_norm_fwd(lname + ".ru norm+prelu+residual", l, outc, dt, U.rawU, U.statsU, P + ".1.conv.unit0.adn.A.weight",
+                           &U.actT, out, U.lidU);
+        } else {
+            U.rawT = B.new_tensor(0, 1, 4); U.actT = B.new_tensor(0, 1, 4);
+            U.statsT = B.stats_alloc((size_t)nb * MI_NSLOT * 2 * sizeof(float));
+            {
+                Step& s = B.push(u.fwd, K_C1_T, lname + ".convT (2C->1)");
+                C1Params& p = s.c1;
+                REL(s, p, y, B_ARENA, cat[0].off); p.y_pitch = K; p.y_coff = 0; p.N = K;
+                REL(s, p, x1_out, B_ARENA, U.rawT.off);
+                REL(s, p, w, B_PARAMS, B.poff(P + ".0.conv.weight") * sizeof(float));
+                REL(s, p, stats, B_ARENA, U.statsT); p.stats_c = 1; p.nstat = 1;
+                p.ndim = nd; p.nb = nb;
+                for (int d = 0; d < 3; ++d) { p.fd[d] = u.rd[0][d]; p.cd[d] = u.rd[1][d]; }
+                s.kernel = dt ? "c1_s2_T_kernel<BF16>" : "c1_s2_T_kernel<F32>";
+                s.work = (double)nb * (u.rp[0] * 4.0 + u.rp[1] * (double)K * esz);
+                u.flops_fwd += 2.0 * nb * u.rp[1] * KK * (double)K;
+            }
+            B.add_norm_fwd(lname + ".convT norm+prelu", 0, 1, 0, U.rawT, U.statsT, P + ".0.adn.A.weight", nullptr, U.actT, U.lidT);
+            {
+                Step& s = B.push(u.fwd, K_STENCIL, lname + ".ru conv (1->1) + identity");
+                StencilParams& p = s.stn;
+                REL(s, p, in, B_ARENA, U.actT.off);
+                REL(s, p, w, B_PARAMS, B.poff(P + ".1.conv.unit0.conv.weight") * sizeof(float));
+                REL(s, p, bias, B_PARAMS, B.poff(P + ".1.conv.unit0.conv.bias") * sizeof(float));
+                REL(s, p, addend, B_ARENA, U.actT.off);
+                REL(s, p, out, B_LOGITS, 0);
+                p.flip = 0; p.ndim = nd; p.nb = nb;
+                for (int d = 0; d < 3; ++d) p.d[d] = u.rd[0][d];
+                s.kernel = "stencil_kernel";
+                s.work = (double)nb * u.rp[0] * 4.0 * 2.0;
+                u.flops_fwd += 2.0 * nb * u.rp[0] * KK;
+            }
+        }
+    }
+    const int n_fwd_packs = (int)u.packs.size();
+    u.n_fwd_packs = n_fwd_packs;
+
+    // ================= backward =================
+    if (train) {
+        B.cur_bucket = 0;
+        {
+            Step& s = B.push(u.bwd, K_MEMSET, "clear backward statistics");
+            REL(s, s.ms, ptr, B_ARENA, u.off_bstats); s.ms.bytes = 0;
+            s.kernel = "hipMemsetAsync";
+        }
+        size_t po, pb; int nslab, nt;
+        // ---- top (up0) ----
+        {
+            const std::string P = uprefix[0];
+            UpSave& U = up[0];
+            const int K = Pcat[0];
+            Ten g_actT = B.new_tensor(0, 1, 4), g_rawT = B.new_tensor(0, 1, 4);
+            {
+                Step& s = B.push(u.bwd, K_STENCIL, "up0.ru conv dgrad + identity");
+                StencilParams& p = s.stn;
+                REL(s, p, in, B_DLOGITS, 0);
+                REL(s, p, w, B_PARAMS, B.poff(P + ".1.conv.unit0.conv.weight") * sizeof(float));
+                REL(s, p, addend, B_DLOGITS, 0);
+                REL(s, p, out, B_ARENA, g_actT.off);
+                p.flip = 1; p.ndim = nd; p.nb = nb;
+                for (int d = 0; d < 3; ++d) p.d[d] = u.rd[0][d];
+                s.kernel = "stencil_kernel";
+                s.work = (double)nb * u.rp[0] * 4.0 * 2.0;
+                u.flops_bwd += 2.0 * nb * u.rp[0] * KK;
+            }
+            {
+                Step& s = B.push(u.bwd, K_STENCIL_WGRAD, "up0.ru conv wgrad");
+                StencilParams& p = s.stn;
+                REL(s, p, in, B_ARENA, U.actT.off);
+                REL(s, p, dout, B_DLOGITS, 0);
+                p.nsplit = 128; p.ndim = nd; p.nb = nb;
+                for (int d = 0; d < 3; ++d) p.d[d] = u.rd[0][d];
+                po = B.alloc((size_t)p.nsplit * KK * sizeof(float)); pb = B.alloc((size_t)p.nsplit * sizeof(float));
+                REL(s, p, partial, B_ARENA, po); REL(s, p, partial_bias, B_ARENA, pb);
+                s.kernel = "stencil_wgrad_kernel";
+                s.work = (double)nb * u.rp[0] * 4.0 * 2.0;
+                u.flops_bwd += 2.0 * nb * u.rp[0] * KK;
+                B.add_reduce(po, pb, p.nsplit, KK, 1, 1, 0, 1, KK, nat, P + ".1.conv.unit0.conv.weight", P + ".1.conv.unit0.conv.bias");
+            }
+            B.add_norm_bwd("up0.convT norm+prelu bwd", 0, 1, 0, g_actT, U.rawT, U.statsT, P + ".0.adn.A.weight", g_rawT, U.lidT);
+            {
+                Step& s = B.push(u.bwd, K_C1_FWD, "up0.convT dgrad (1->2C conv s2)");
+                C1Params& p = s.c1;
+                REL(s, p, x1, B_ARENA, g_rawT.off);
+                REL(s, p, y_out, B_ARENA, gcat[0].off); p.y_pitch = K; p.y_coff = 0; p.N = K;
+                REL(s, p, w, B_PARAMS, B.poff(P + ".0.conv.weight") * sizeof(float)); p.n_w1 = K;
+                p.ndim = nd; p.nb = nb;
+                for (int d = 0; d < 3; ++d) { p.fd[d] = u.rd[0][d]; p.cd[d] = u.rd[1][d]; }
+                s.kernel = dt ? "c1_s2_fwd_kernel<BF16>" : "c1_s2_fwd_kernel<F32>";
+                s.work = (double)nb * (u.rp[0] * 4.0 + u.rp[1] * (double)K * esz);
+                u.flops_bwd += 2.0 * nb * u.rp[1] * KK * (double)K;
+            }
+            {
+                Step& s = B.push(u.bwd, K_C1_WGRAD, "up0.convT wgrad");
+                C1Params& p = s.c1;
+                REL(s, p, y, B_ARENA, cat[0].off); p.y_pitch = K; p.y_coff = 0; p.N = K;
+                REL(s, p, x1, B_ARENA, g_rawT.off);
+                p.ndim = nd; p.nb = nb; p.nsplit = 256;
+                for (int d = 0; d < 3; ++d) { p.fd[d] = u.rd[0][d]; p.cd[d] = u.rd[1][d]; }
+                po = B.alloc((size_t)p.nsplit * KK * K * sizeof(float)); pb = B.alloc((size_t)p.nsplit * K * sizeof(float));
+                REL(s, p, partial, B_ARENA, po); REL(s, p, partial_bias, B_ARENA, pb);
+                s.kernel = dt ? "c1_s2_wgrad_kernel<BF16>" : "c1_s2_wgrad_kernel<F32>";
+                s.work = (double)nb * (u.rp[0] * 4.0 + u.rp[1] * (double)K * esz);
+                u.flops_bwd += 2.0 * nb * u.rp[1] * KK * (double)K;
+                B.add_reduce(po, pb, p.nsplit, KK, K, 1, 0, K, KK, nat, P + ".0.conv.weight", "");
+                B.add_scalar_reduce(0, 0, P + ".0.conv.bias");  // feeds an instance norm: gradient is exactly zero
+            }
+        }
+        // ---- up l = 1 .. L-2 ----
+        for (int l = 1; l <= L - 2; ++l) {
+            const std::string P = uprefix[l];
+            const std::string lname = "up" + std::to_string(l);
+            UpSave& U = up[l];
+            const int outc = c[l - 1], K = Pcat[l];
+            Ten dout = gcat[l - 1]; dout.coff = c[l - 1];
+            Ten g_rawU = B.new_tensor(l, outc, esz), g_actT = B.new_tensor(l, outc, esz), g_rawT = B.new_tensor(l, outc, esz);
+            B.add_norm_bwd(lname + ".ru norm+prelu bwd", l, outc, dt, dout, U.rawU, U.statsU, P + ".1.conv.unit0.adn.A.weight", g_rawU, U.lidU);
+            ConvShape cu = B.shape(0, 3, 1, outc, outc, l);
+            U.wU_d = B.packed_alloc(KK, outc, outc);
+            if (!B.add_igemm(u.bwd, lname + ".ru conv dgrad", cu, DIR_DGRAD, g_rawU, outc, nullptr, outc, outc, U.wU_d, nullptr, 0,
+                             g_actT, &dout, (size_t)-1, 0, 0, kidx, &ntaps))
+                return false;
+            B.add_pack(true, U.wU_d, P + ".1.conv.unit0.conv.weight", outc, outc, ntaps, kidx, KK, outc * KK, outc, outc, 0, 0);
+            B.add_wgrad(lname + ".ru conv wgrad", cu, g_rawU, outc, nullptr, outc, U.actT, outc, &po, &pb, &nslab, &nt);
+            B.add_reduce(po, pb, nslab, nt, outc, outc, 0, outc, KK, nat, P + ".1.conv.unit0.conv.weight", P + ".1.conv.unit0.conv.bias");
+            B.add_norm_bwd(lname + ".convT norm+prelu bwd", l, outc, dt, g_actT, U.rawT, U.statsT, P + ".0.adn.A.weight", g_rawT, U.lidT);
+            ConvShape ct = B.shape(1, 3, 2, K, outc, l + 1);
+            U.wT_d = B.packed_alloc(KK, K, outc);
+            if (!B.add_igemm(u.bwd, lname + ".convT dgrad", ct, DIR_DGRAD, g_rawT, outc, nullptr, outc, K, U.wT_d, nullptr, 0,
+                             gcat[l], nullptr, (size_t)-1, 0, 0, kidx, &ntaps))
+                return false;
+            B.add_pack(true, U.wT_d, P + ".0.conv.weight", K, outc, ntaps, kidx, outc * KK, KK, K, outc, 0, 0);
+            B.add_wgrad(lname + ".convT wgrad", ct, cat[l], K, nullptr, K, g_rawT, outc, &po, &pb, &nslab, &nt);
+            B.add_reduce(po, pb, nslab, nt, K, outc, 0, K, KK, nat, P + ".0.conv.weight", "");
+            B.add_scalar_reduce(0, 0, P + ".0.conv.bias", outc);
+        }
+        { Step& s = B.push(u.bwd, K_REDUCE, "reduce gradients: decoder bucket"); s.kernel = "reduce_kernel"; }
+        // ---- bottom ----
+        B.cur_bucket = 1;
+        {
+            const int cin = c[L - 2], cout = c[L - 1], res = L - 1;
+            const std::string P = botprefix;
+            Ten dout = gcat[L - 2]; dout.coff = cin;
+            Ten gin = gcat[L - 2]; gin.coff = 0;
+            Ten in = cat[L - 2]; in.coff = 0;
+            Ten g_raw = B.new_tensor(res, cout, esz);
+            B.add_norm_bwd("bottom.unit" + std::to_string(R - 1) + " norm+prelu bwd", res, cout, dt, dout, bot.un[R - 1].raw,
+                           bot.un[R - 1].stats, bot.un[R - 1].alpha, g_raw, bot.un[R - 1].lid);
+            for (int su = R - 1; su >= 1; --su) {
+                UnitSave& U = bot.un[su];
+                Ten g_act = B.new_tensor(res, cout, esz);
+                ConvShape cs = B.shape(0, 3, 1, cout, cout, res);
+                U.wdg = B.packed_alloc(KK, cout, cout);
+                if (!B.add_igemm(u.bwd, "bottom.unit" + std::to_string(su) + " conv dgrad", cs, DIR_DGRAD, g_raw, cout, nullptr,
+                                 cout, cout, U.wdg, nullptr, 0, g_act, nullptr, (size_t)-1, 0, 0, kidx, &ntaps))
+                    return false;
+                B.add_pack(true, U.wdg, U.wname, cout, cout, ntaps, kidx, KK, cout * KK, cout, cout, 0, 0);
+                B.add_wgrad("bottom.unit" + std::to_string(su) + " conv wgrad", cs, g_raw, cout, nullptr, cout, bot.un[su - 1].act,
+                            cout, &po, &pb, &nslab, &nt);
+                B.add_reduce(po, pb, nslab, nt, cout, cout, 0, cout, KK, nat, U.wname, U.bname);
+                Ten g_raw_prev = B.new_tensor(res, cout, esz);
+                B.add_norm_bwd("bottom.unit" + std::to_string(su - 1) + " norm+prelu bwd", res, cout, dt, g_act, bot.un[su - 1].raw,
+                               bot.un[su - 1].stats, bot.un[su - 1].alpha, g_raw_prev, bot.un[su - 1].lid);
+                g_raw = g_raw_prev;
+            }
+            {
+                UnitSave& U = bot.un[0];
+                ConvShape cs = B.shape(0, 3, 1, cin, cout, res);
+                U.wdg = B.packed_alloc(KK, cin, cout);
+                if (!B.add_igemm(u.bwd, "bottom.unit0 conv dgrad (+=)", cs, DIR_DGRAD, g_raw, cout, nullptr, cout, cin, U.wdg,
+                                 nullptr, 0, gin, &gin, (size_t)-1, 0, 0, kidx, &ntaps))
+                    return false;
+                B.add_pack(true, U.wdg, U.wname, cin, cout, ntaps, kidx, KK, cin * KK, cin, cout, 0, 0);
+                B.add_wgrad("bottom.unit0 conv wgrad", cs, g_raw, cout, nullptr, cout, in, cin, &po, &pb, &nslab, &nt);
+                B.add_reduce(po, pb, nslab, nt, cout, cin, 0, cout, KK, nat, U.wname, U.bname);
+            }
+            if (bot.has_res_conv) {
+                ConvShape cr = B.shape(0, 1, 1, cin, cout, res);
+                bot.wres_d = B.packed_alloc(1, cin, cout);
+                if (!B.add_igemm(u.bwd, "bottom.residual conv 1x1 dgrad (+=)", cr, DIR_DGRAD, dout, cout, nullptr, cout, cin,
+                                 bot.wres_d, nullptr, 0, gin, &gin, (size_t)-1, 0, 0, kidx, &ntaps))
+                    return false;
+                B.add_pack(true, bot.wres_d, P + ".residual.weight", cin, cout, ntaps, kidx, 1, cin, cin, cout, 0, 0);
+                B.add_wgrad("bottom.residual conv 1x1 wgrad", cr, dout, cout, nullptr, cout, in, cin, &po, &pb, &nslab, &nt);
+                B.add_reduce(po, pb, nslab, nt, cout, cin, 0, cout, 1, nat, P + ".residual.weight", P + ".residual.bias");
+            } else {
+                Step& s = B.push(u.bwd, K_ADD, "bottom identity residual (+=)");
+                REL(s, s.add, dst, B_ARENA, gin.off); s.add.dpitch = gin.pitch; s.add.dcoff = 0;
+                REL(s, s.add, src, B_ARENA, dout.off); s.add.spitch = dout.pitch; s.add.scoff = dout.coff;
+                s.add.c = cin; s.add.npix = (long long)nb * u.rp[res];
+                s.kernel = "add_kernel";
+                s.work = (double)nb * u.rp[res] * cin * esz * 3.0;
+            }
+        }
+        { Step& s = B.push(u.bwd, K_REDUCE, "reduce gradients: bottom bucket"); s.kernel = "reduce_kernel"; }
+        // ---- down path ----
+        B.cur_bucket = 2;
+        for (int l = L - 2; l >= 0; --l) {
+            const int cin = l == 0 ? 1 : c[l - 1], cout = c[l];
+            const std::string P = dprefix[l];
+            const std::string lname = "down" + std::to_string(l);
+            DownSave& D = down[l];
+            Ten dout = gcat[l]; dout.coff = 0;
+            Ten g_raw = B.new_tensor(l + 1, cout, esz);
+            B.add_norm_bwd(lname + ".unit" + std::to_string(R - 1) + " norm+prelu bwd", l + 1, cout, dt, dout, D.un[R - 1].raw,
+                           D.un[R - 1].stats, D.un[R - 1].alpha, g_raw, D.un[R - 1].lid);
+            for (int su = R - 1; su >= 1; --su) {
+                UnitSave& U = D.un[su];
+                Ten g_act = B.new_tensor(l + 1, cout, esz);
+                ConvShape cs = B.shape(0, 3, 1, cout, cout, l + 1);
+                U.wdg = B.packed_alloc(KK, cout, cout);
+                if (!B.add_igemm(u.bwd, lname + ".unit" + std::to_string(su) + " conv dgrad", cs, DIR_DGRAD, g_raw, cout, nullptr,
+                                 cout, cout, U.wdg, nullptr, 0, g_act, nullptr, (size_t)-1, 0, 0, kidx, &ntaps))
+                    return false;
+                B.add_pack(true, U.wdg, U.wname, cout, cout, ntaps, kidx, KK, cout * KK, cout, cout, 0, 0);
+                B.add_wgrad(lname + ".unit" + std::to_string(su) + " conv wgrad", cs, g_raw, cout, nullptr, cout, D.un[su - 1].act,
+                            cout, &po, &pb, &nslab, &nt);
+                B.add_reduce(po, pb, nslab, nt, cout, cout, 0, cout, KK, nat, U.wname, U.bname);
+                Ten g_raw_prev = B.new_tensor(l + 1, cout, esz);
+                B.add_norm_bwd(lname + ".unit" + std::to_string(su - 1) + " norm+prelu bwd", l + 1, cout, dt, g_act, D.un[su - 1].raw,
+                               D.un[su - 1].stats, D.un[su - 1].alpha, g_raw_prev, D.un[su - 1].lid);
+                g_raw = g_raw_prev;
+            }
+            if (l > 0) {
+                ConvShape cs = B.shape(0, 3, 2, cin, 2 * cout, l);
+                Ten gin = gcat[l - 1]; gin.coff = 0;
+                Ten in = cat[l - 1]; in.coff = 0;
+                D.wd = B.packed_alloc(KK, cin, 2 * cout);
+                if (!B.add_igemm(u.bwd, lname + ".unit0+residual conv s2 dgrad (+=)", cs, DIR_DGRAD, g_raw, cout, &dout, 2 * cout,
+                                 cin, D.wd, nullptr, 0, gin, &gin, (size_t)-1, 0, 0, kidx, &ntaps))
+                    return false;
+                B.add_pack(true, D.wd, D.un[0].wname, cin, cout, ntaps, kidx, KK, cin * KK, cin, 2 * cout, 0, 0);
+                B.add_pack(true, D.wd, P + ".residual.weight", cin, cout, ntaps, kidx, KK, cin * KK, cin, 2 * cout, 0, cout);
+                B.add_wgrad(lname + ".unit0+residual conv s2 wgrad", cs, g_raw, cout, &dout, 2 * cout, in, cin, &po, &pb, &nslab, &nt);
+                B.add_reduce(po, pb, nslab, nt, 2 * cout, cin, 0, cout, KK, nat, D.un[0].wname, D.un[0].bname);
+                B.add_reduce(po, pb, nslab, nt, 2 * cout, cin, cout, cout, KK, nat, P + ".residual.weight", P + ".residual.bias");
+            } else {
+                for (int half = 0; half < 2; ++half) {
+                    Step& s = B.push(u.bwd, K_C1_WGRAD, half == 0 ? "down0.unit0 conv wgrad" : "down0.residual conv wgrad");
+                    C1Params& p = s.c1;
+                    const Ten& y = half == 0 ? g_raw : dout;
+                    REL(s, p, y, B_ARENA, y.off); p.y_pitch = y.pitch; p.y_coff = y.coff; p.N = cout;
+                    REL(s, p, x1, B_XIN, 0);
+                    p.ndim = nd; p.nb = nb; p.nsplit = 256;
+                    for (int d = 0; d < 3; ++d) { p.fd[d] = u.rd[0][d]; p.cd[d] = u.rd[1][d]; }
+                    po = B.alloc((size_t)p.nsplit * KK * cout * sizeof(float)); pb = B.alloc((size_t)p.nsplit * cout * sizeof(float));
+                    REL(s, p, partial, B_ARENA, po); REL(s, p, partial_bias, B_ARENA, pb);
+                    s.kernel = dt ? "c1_s2_wgrad_kernel<BF16>" : "c1_s2_wgrad_kernel<F32>";
+                    s.work = (double)nb * (u.rp[0] * 4.0 + u.rp[1] * (double)cout * esz);
+                    u.flops_bwd += 2.0 * nb * u.rp[1] * KK * (double)cout;
+                    if (half == 0) B.add_reduce(po, pb, p.nsplit, KK, cout, 1, 0, cout, KK, nat, D.un[0].wname, D.un[0].bname);
+                    else B.add_reduce(po, pb, p.nsplit, KK, cout, 1, 0, cout, KK, nat, P + ".residual.weight", P + ".residual.bias");
+                }
+            }
+        }
+        { Step& s = B.push(u.bwd, K_REDUCE, "reduce gradients: encoder bucket"); s.kernel = "reduce_kernel"; }
+    }
+
+    // ---- descriptor tables ----
+    // reorder packs so that the forward packs come first (they already do: backward packs were appended later)
+    u.off_pack_tab = B.alloc(u.packs.size() * sizeof(PackDesc) + 256);
+    u.off_reduce_tab = B.alloc(u.reduces.size() * sizeof(ReduceDesc) + 256);
+    // reduces are grouped by bucket in creation order; find ranges
+    {
+        int first[3] = {-1, -1, -1}, cnt[3] = {0, 0, 0};
+        for (size_t i = 0; i < B.bucket_of_reduce.size(); ++i) {
+            const int b = B.bucket_of_reduce[i];
+            if (first[b] < 0) first[b] = (int)i;
+            cnt[b]++;
+        }
+        int k = 0;
+        for (Step& s : u.bwd)
+            if (s.kind == K_REDUCE) {
+                s.tab.first = first[k] < 0 ? 0 : first[k]; s.tab.count = cnt[k];
+                int mx = 1;
+                for (int i = s.tab.first; i < s.tab.first + s.tab.count; ++i) {
+                    const ReduceDesc& d = u.reduces[i];
+                    const int e = d.ntaps * d.Fcnt * d.S + d.Fcnt;
+                    if (e > mx) mx = e;
+                }
+                s.tab.max_elems = mx;
+                ++k;
+            }
+    }
+    for (Step& s : u.fwd) {
+        if (s.kind == K_PACK) {
+            s.tab.first = 0; s.tab.count = (int)u.packs.size();  // forward and backward packs in one launch
+            if (!train) s.tab.count = n_fwd_packs;
+            int mx = 1;
+            for (int i = 0; i < s.tab.count; ++i) { const int e = u.packs[i].ntaps * u.packs[i].N * u.packs[i].K; if (e > mx) mx = e; }
+            s.tab.max_elems = mx;
+        }
+        if (s.kind == K_MEMSET) s.ms.bytes = align_up(B.stats_cursor, 16);
+    }
+    for (Step& s : u.bwd)
+        if (s.kind == K_MEMSET) s.ms.bytes = align_up(B.bstats_cursor, 16);
+    if (B.stats_cursor > u.stats_bytes || B.bstats_cursor > u.bstats_bytes) { mi_set_error("statistics region overflow"); return false; }
+    return true;
+}
+
+int upload_tables(mi_unet& u, char* const* bases, bool want_reduce, hipStream_t st) {
+    if (u.cached_pack_bases[0] != bases[B_ARENA] || u.cached_pack_bases[1] != bases[B_PARAMS]) {
+        u.packs_res = u.packs;
+        for (PackDesc& d : u.packs_res) {
+            d.src = reinterpret_cast<const float*>(bases[B_PARAMS] + reinterpret_cast<uintptr_t>(d.src));
+            d.dst = bases[B_ARENA] + reinterpret_cast<uintptr_t>(d.dst);
+        }
+        if (!u.packs_res.empty())
+            MI_HIP(hipMemcpyAsync(bases[B_ARENA] + u.off_pack_tab, u.packs_res.data(), u.packs_res.size() * sizeof(PackDesc),
+                                  hipMemcpyHostToDevice, st));
+        u.cached_pack_bases[0] = bases[B_ARENA]; u.cached_pack_bases[1] = bases[B_PARAMS];
+    }
+    if (want_reduce && (u.cached_reduce_bases[0] != bases[B_ARENA] || u.cached_reduce_bases[1] != bases[B_GRADS])) {
+        u.reduces_res = u.reduces;
+        for (size_t i = 0; i < u.reduces_res.size(); ++i) {
+            ReduceDesc& d = u.reduces_res[i];
+            d.partial = reinterpret_cast<const float*>(bases[B_ARENA] + reinterpret_cast<uintptr_t>(d.partial));
+            d.partial_bias = reinterpret_cast<const float*>(bases[B_ARENA] + reinterpret_cast<uintptr_t>(d.partial_bias));
+            d.dst_w = reinterpret_cast<float*>(bases[B_GRADS] + reinterpret_cast<uintptr_t>(d.dst_w));
+            d.dst_b = u.reduce_has_b[i] ? reinterpret_cast<float*>(bases[B_GRADS] + reinterpret_cast<uintptr_t>(d.dst_b)) : nullptr;
+        }
+        if (!u.reduces_res.empty())
+            MI_HIP(hipMemcpyAsync(bases[B_ARENA] + u.off_reduce_tab, u.reduces_res.data(),
+                                  u.reduces_res.size() * sizeof(ReduceDesc), hipMemcpyHostToDevice, st));
+        u.cached_reduce_bases[0] = bases[B_ARENA]; u.cached_reduce_bases[1] = bases[B_GRADS];
+    }
+    return 0;
+}
+
+int run_step(mi_unet& u, Step& s, char* const* bases, int training, uint64_t seed, hipStream_t st) {
+    switch (s.kind) {
+        case K_IGEMM: return launch_igemm(s.dtype, resolve(s, s.ig, bases), st);
+        case K_WGRAD: return launch_wgrad(s.dtype, resolve(s, s.wg, bases), st);
+        case K_NORM_FWD:
+        case K_NORM_BWD: {
+            NormParams p = resolve(s, s.nm, bases);
+            p.seed = seed;
+            if (training && u.cfg.dropout > 0.f) {
+                double t = (double)u.cfg.dropout * 4294967296.0;
+                p.drop_thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+                p.drop_scale = 1.0f / (1.0f - u.cfg.dropout);
+            } else { p.drop_thresh = 0; p.drop_scale = 1.f; }
+            return s.kind == K_NORM_FWD ? launch_norm_fwd(s.dtype, p, st) : launch_norm_bwd(s.dtype, p, st);
+        }
+        case K_C1_FWD: return launch_c1_s2_fwd(s.dtype, resolve(s, s.c1, bases), st);
+        case K_C1_T: return launch_c1_s2_T(s.dtype, resolve(s, s.c1, bases), st);
+        case K_C1_WGRAD: return launch_c1_s2_wgrad(s.dtype, resolve(s, s.c1, bases), st);
+        case K_STENCIL: return launch_stencil(resolve(s, s.stn, bases), st);
+        case K_STENCIL_WGRAD: return launch_stencil_wgrad(resolve(s, s.stn, bases), st);
+        case K_ADD: {
+            AddArgs a = resolve(s, s.add, bases);
+            return launch_add(s.dtype, a.dst, a.dpitch, a.dcoff, a.src, a.spitch, a.scoff, a.c, a.npix, st);
+        }
+        case K_MEMSET: {
+            MemsetArgs m = resolve(s, s.ms, bases);
+            if (m.bytes) MI_HIP(hipMemsetAsync(m.ptr, 0, m.bytes, st));
+            return 0;
+        }
+        case K_REDUCE:
+            return launch_reduce(reinterpret_cast<const ReduceDesc*>(bases[B_ARENA] + u.off_reduce_tab) + s.tab.first,
+                                 s.tab.count, s.tab.max_elems, st);
+        case K_PACK:
+            return launch_pack(s.dtype, reinterpret_cast<const PackDesc*>(bases[B_ARENA] + u.off_pack_tab) + s.tab.first,
+                               s.tab.count, s.tab.max_elems, st);
+    }
+    mi_set_error("unknown step kind");
+    return -1;
+}
+
+int run_list(mi_unet& u, std::vector<Step>& list, int backward, int bucket, char* const* bases, int training, uint64_t seed,
+             hipStream_t st) {
+    for (size_t i = 0; i < list.size(); ++i) {
+        Step& s = list[i];
+        if (bucket >= 0 && s.bucket != bucket) continue;
+        ProfEvent ev;
+        if (u.prof) {
+            MI_HIP(hipEventCreate(&ev.a)); MI_HIP(hipEventCreate(&ev.b));
+            MI_HIP(hipEventRecord(ev.a, st));
+        }
+        if (int r = run_step(u, s, bases, training, seed, st)) return r;
+        if (u.prof) {
+            MI_HIP(hipEventRecord(ev.b, st));
+            ev.backward = backward; ev.step = (int)i;
+            u.events.push_back(ev);
+        }
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi_unet_create(const mi_unet_cfg* cfg, mi_unet** out) {
+    MI_CHECK(cfg && out, "null argument");
+    MI_CHECK(cfg->spatial_dims == 2 || cfg->spatial_dims == 3, "spatial_dims must be 2 or 3");
+    MI_CHECK(cfg->in_channels == 1 && cfg->out_channels == 1, "the HIP path implements in_channels = out_channels = 1");
+    MI_CHECK(cfg->n_levels >= 2 && cfg->n_levels <= 8, "2 <= len(channels) <= 8");
+    MI_CHECK(cfg->num_res_units >= 1 && cfg->num_res_units <= 4, "1 <= num_res_units <= 4");
+    MI_CHECK(cfg->dropout >= 0.f && cfg->dropout < 1.f, "0 <= dropout < 1");
+    MI_CHECK(cfg->dtype == 0 || cfg->dtype == 1, "dtype must be 0 (fp32) or 1 (bf16)");
+    MI_CHECK(cfg->batch >= 1, "batch must be positive");
+    for (int i = 0; i < cfg->n_levels; ++i) MI_CHECK(cfg->channels[i] % 16 == 0 && cfg->channels[i] >= 16 && cfg->channels[i] <= 1024, "channels must be multiples of 16 in [16, 1024]");
+    for (int i = 0; i < cfg->n_levels - 1; ++i) MI_CHECK(cfg->strides[i] == 2, "strides must all be 2");
+    MI_CHECK(cfg->channels[0] <= 128, "channels[0] must be at most 128");
+    const int div = 1 << (cfg->n_levels - 1);
+    for (int d = 0; d < 3; ++d) {
+        if (cfg->spatial_dims == 2 && d == 0) { MI_CHECK(cfg->dims[0] == 1, "dims[0] must be 1 in 2-D"); continue; }
+        MI_CHECK(cfg->dims[d] >= div && cfg->dims[d] % div == 0, "every spatial size must be divisible by 2^(len(channels)-1)");
+    }
+    mi_unet* u = new mi_unet();
+    u->cfg = *cfg;
+    u->L = cfg->n_levels; u->R = cfg->num_res_units; u->nd = cfg->spatial_dims; u->dt = cfg->dtype;
+    u->esz = cfg->dtype ? 2 : 4; u->nb = cfg->batch;
+    u->KK = cfg->spatial_dims == 3 ? 27 : 9;
+    for (int r = 0; r < u->L; ++r) {
+        u->rp[r] = 1;
+        for (int d = 0; d < 3; ++d) {
+            u->rd[r][d] = (cfg->spatial_dims == 2 && d == 0) ? 1 : cfg->dims[d] >> r;
+            u->rp[r] *= u->rd[r][d];
+        }
+    }
+    {
+        const long long big = (long long)u->nb * u->rp[0] * 2 * cfg->channels[0];
+        if (big > 2000000000LL) { delete u; mi_set_error("mi_unet_create: batch * pixels too large for 32-bit pixel indices"); return -1; }
+    }
+    enum_params(*u);
+    if (!build(*u)) { delete u; return -1; }
+    *out = u;
+    return 0;
+}
+
+void mi_unet_destroy(mi_unet* u) {
+    if (!u) return;
+    for (ProfEvent& e : u->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    delete u;
+}
+
+int mi_unet_num_params(const mi_unet* u) { return (int)u->params.size(); }
+
+int mi_unet_param_info(const mi_unet* u, int i, mi_param_info* info) {
+    MI_CHECK(u && info && i >= 0 && i < (int)u->params.size(), "bad index");
+    const ParamRec& r = u->params[i];
+    memset(info, 0, sizeof(*info));
+    snprintf(info->name, sizeof(info->name), "%s", r.name.c_str());
+    info->ndim = r.ndim;
+    for (int k = 0; k < 5; ++k) info->shape[k] = r.shape[k];
+    info->numel = r.numel; info->offset = r.offset; info->bucket = r.bucket;
+    return 0;
+}
+
+int64_t mi_unet_param_floats(const mi_unet* u) { return u->nfloats; }
+size_t mi_unet_workspace_bytes(const mi_unet* u) { return u->arena; }
+
+int mi_unet_bucket_range(const mi_unet* u, int bucket, int64_t* offset, int64_t* count) {
+    MI_CHECK(u && bucket >= 0 && bucket < 3, "bad bucket");
+    *offset = u->bucket_off[bucket]; *count = u->bucket_cnt[bucket];
+    return 0;
+}
+
+double mi_unet_flops(const mi_unet* u, int backward) { return backward ? u->flops_bwd : u->flops_fwd; }
+int mi_unet_num_steps(const mi_unet* u, int backward) { return (int)(backward ? u->bwd.size() : u->fwd.size()); }
+
+int mi_unet_forward(mi_unet* u, const float* params, const float* x, float* logits, void* workspace, int training,
+                    uint64_t seed, void* stream) {
+    MI_CHECK(u && params && x && logits && workspace, "null argument");
+    char* bases[B_NBASE] = {nullptr};
+    bases[B_ARENA] = (char*)workspace; bases[B_PARAMS] = (char*)params; bases[B_XIN] = (char*)x; bases[B_LOGITS] = (char*)logits;
+    hipStream_t st = (hipStream_t)stream;
+    if (int r = upload_tables(*u, bases, false, st)) return r;
+    return run_list(*u, u->fwd, 0, -1, bases, training, seed, st);
+}
+
+int mi_unet_backward(mi_unet* u, const float* params, const float* dlogits, float* grads, void* workspace, int training,
+                     uint64_t seed, int bucket, void* stream) {
+    MI_CHECK(u && params && dlogits && grads && workspace, "null argument");
+    MI_CHECK(u->cfg.with_backward, "plan was created without a backward pass");
+    MI_CHECK(bucket < 3, "bucket must be < 3");
+    char* bases[B_NBASE] = {nullptr};
+    bases[B_ARENA] = (char*)workspace; bases[B_PARAMS] = (char*)params; bases[B_GRADS] = (char*)grads;
+    bases[B_DLOGITS] = (char*)dlogits;
+    hipStream_t st = (hipStream_t)stream;
+    if (int r = upload_tables(*u, bases, true, st)) return r;
+    return run_list(*u, u->bwd, 1, bucket, bases, training, seed, st);
+}
+
+int mi_unet_prof_enable(mi_unet* u, int on) { u->prof = on != 0; return 0; }
+
+int mi_unet_prof_collect(mi_unet* u) {
+    for (ProfEvent& e : u->events) {
+        MI_HIP(hipEventSynchronize(e.b));
+        float ms = 0.f;
+        MI_HIP(hipEventElapsedTime(&ms, e.a, e.b));
+        Step& s = e.backward ? u->bwd[e.step] : u->fwd[e.step];
+        s.total_ms += ms; s.launches += 1;
+        (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
+    }
+    u->events.clear();
+    return 0;
+}
+
+int mi_unet_prof_reset(mi_unet* u) {
+    for (Step& s : u->fwd) { s.total_ms = 0; s.launches = 0; }
+    for (Step& s : u->bwd) { s.total_ms = 0; s.launches = 0; }
+    return 0;
+}
+
+int mi_unet_step_info(const mi_unet* u, int backward, int i, mi_step_info* info) {
+    const std::vector<Step>& l = backward ? u->bwd : u->fwd;
+    MI_CHECK(i >= 0 && i < (int)l.size() && info, "bad index");
+    const Step& s = l[i];
+    memset(info, 0, sizeof(*info));
+    snprintf(info->layer, sizeof(info->layer), "%s", s.layer.c_str());
+    snprintf(info->kernel, sizeof(info->kernel), "%s", s.kernel.c_str());
+    info->work = s.work; info->work_is_flops = s.work_is_flops; info->total_ms = s.total_ms; info->launches = s.launches;
+    return 0;
+}
+
+// ---------------- loss / metric / optimizer / sliding window ----------------
+int mi_dice_ce_loss_fwd(const float* logits, const void* target, int target_dtype, int fold2, int nb, int64_t npix,
+                        float smooth_nr, float smooth_dr, float lambda_dice, float lambda_ce, float* sums, float* loss,
+                        float* loss_accum, void* stream) {
+    MI_CHECK(logits && target && sums && loss, "null argument");
+    MI_CHECK(npix > 0 && npix < 2147483647LL && nb > 0, "bad sizes");
+    LossParams p; memset(&p, 0, sizeof(p));
+    p.logits = logits; p.target = target; p.tdtype = target_dtype; p.fold2 = fold2; p.sums = sums; p.loss = loss;
+    p.loss_accum = loss_accum; p.nb = nb; p.npix = (int)npix; p.smooth_nr = smooth_nr; p.smooth_dr = smooth_dr;
+    p.lambda_dice = lambda_dice; p.lambda_ce = lambda_ce;
+    return launch_loss_fwd(p, (hipStream_t)stream);
+}
+
+int mi_dice_ce_loss_bwd(const float* logits, const void* target, int target_dtype, int fold2, int nb, int64_t npix,
+                        float smooth_nr, float smooth_dr, float lambda_dice, float lambda_ce, const float* sums,
+                        const float* grad_out, float grad_scale, float* dlogits, void* stream) {
+    MI_CHECK(logits && target && sums && dlogits, "null argument");
+    MI_CHECK(npix > 0 && npix < 2147483647LL && nb > 0, "bad sizes");
+    LossParams p; memset(&p, 0, sizeof(p));
+    p.logits = logits; p.target = target; p.tdtype = target_dtype; p.fold2 = fold2; p.sums = const_cast<float*>(sums);
+    p.dlogits = dlogits; p.gout = grad_out; p.gscale = grad_scale; p.nb = nb; p.npix = (int)npix;
+    p.smooth_nr = smooth_nr; p.smooth_dr = smooth_dr; p.lambda_dice = lambda_dice; p.lambda_ce = lambda_ce;
+    return launch_loss_bwd(p, (hipStream_t)stream);
+}
+
+int mi_dice_counts(const float* pred, int pred_is_binary, float thresh, const void* target, int target_dtype, int fold2,
+                   int nb, int64_t npix, uint64_t* counts, void* stream) {
+    MI_CHECK(pred && target && counts, "null argument");
+    MI_CHECK(npix > 0 && npix < 2147483647LL && nb > 0, "bad sizes");
+    CountParams p; memset(&p, 0, sizeof(p));
+    p.pred = pred; p.pred_is_binary = pred_is_binary; p.thresh = thresh; p.target = target; p.tdtype = target_dtype;
+    p.fold2 = fold2; p.counts = (unsigned long long*)counts; p.nb = nb; p.npix = (int)npix;
+    return launch_dice_counts(p, (hipStream_t)stream);
+}
+
+int mi_fold_labels(void* target, int target_dtype, int64_t n, void* stream) {
+    MI_CHECK(target && n >= 0, "bad argument");
+    return launch_fold_labels(target, target_dtype, n, (hipStream_t)stream);
+}
+
+int mi_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int64_t step, float grad_scale, void* stream) {
+    MI_CHECK(params && grads && exp_avg && exp_avg_sq && n > 0 && step >= 1, "bad argument");
+    MI_CHECK((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0, "buffers must be 16-byte aligned");
+    AdamParams p;
+    p.param = params; p.grad = grads; p.m = exp_avg; p.v = exp_avg_sq; p.n = n;
+    p.decay = 1.0f - lr * weight_decay; p.beta1 = beta1; p.beta2 = beta2; p.eps = eps;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    p.step_size = (float)((double)lr / bc1); p.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2)); p.gscale = grad_scale;
+    return launch_adamw(p, (hipStream_t)stream);
+}
+
+int mi_sw_gather(const float* image, float* windows, const int32_t* starts, int nwin, int win0, int nwin_launch, int nb,
+                 const int32_t img[3], const int32_t roi[3], const int32_t pad_lo[3], float cval, void* stream) {
+    MI_CHECK(image && windows && starts && nwin > 0 && nwin_launch > 0, "bad argument");
+    SwParams p; memset(&p, 0, sizeof(p));
+    p.image = image; p.windows = windows; p.starts = starts; p.nwin = nwin; p.win0 = win0; p.nb = nb; p.cval = cval;
+    for (int d = 0; d < 3; ++d) { p.img[d] = img[d]; p.roi[d] = roi[d]; p.pad_lo[d] = pad_lo[d]; }
+    return launch_sw_gather(p, nwin_launch, (hipStream_t)stream);
+}
+
+int mi_sw_blend(const float* win_out, float* out, const int32_t* starts, int nwin, int nb, const int32_t img[3],
+                const int32_t roi[3], const int32_t pad_lo[3], void* stream) {
+    MI_CHECK(win_out && out && starts && nwin > 0, "bad argument");
+    SwParams p; memset(&p, 0, sizeof(p));
+    p.win_out = win_out; p.out = out; p.starts = starts; p.nwin = nwin; p.nb = nb;
+    for (int d = 0; d < 3; ++d) { p.img[d] = img[d]; p.roi[d] = roi[d]; p.pad_lo[d] = pad_lo[d]; }
+    return launch_sw_blend(p, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,673 @@
+// Gather-GEMM convolution kernels for gfx950 (MI355X): forward / data-gradient and
+// weight-gradient of 3x3(x3) and 1x1 convolutions and stride-2 transposed convolutions,
+// on channels-last tensors, with MFMA (bf16 16x16x32 or exact-fp32 16x16x4).
+//
+// Forward / dgrad tile: 256 base pixels x (16*NFRAG) output channels per 256-thread
+// workgroup.  The input patch (tile + halo) of one contraction chunk is staged in LDS
+// once and re-used by every tap; the weight tile of the chunk is staged next to it.
+// MFMA roles are swapped on purpose (A = weights, B = pixels) so that every lane ends
+// up with consecutive channels of ONE pixel: channels-last stores are 16-byte vectors
+// and the instance-norm statistics reduce over the 16 lanes that share a channel.
+#include "common.h"
+#include "kparams.h"
+
+namespace {
+
+template <class TR>
+__device__ __forceinline__ v4f mma16(const uint4& a, const uint4& b, v4f c);
+template <>
+__device__ __forceinline__ v4f mma16<BF16>(const uint4& a, const uint4& b, v4f c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b), c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ v4f mma16<F32>(const uint4& a, const uint4& b, v4f c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    return c;
+}
+
+// channel (within the workgroup's N tile) held by MFMA row `rr` of fragment `nf`
+template <int NFRAG>
+__device__ __forceinline__ int chan_of_row(int nf, int rr) {
+    if (NFRAG == 1) return rr;
+    return 32 * (nf >> 1) + 8 * (rr >> 2) + 4 * (nf & 1) + (rr & 3);
+}
+
+// ---------------------------------------------------------------------------------
+// forward / dgrad
+// ---------------------------------------------------------------------------------
+template <class TR, int CPS, int NFRAG>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
+    constexpr int ESZ = TR::ESZ;
+    constexpr int KCB = CPS * 16;    // contraction bytes per pixel per stage
+    constexpr int KCE = KCB / ESZ;   // ... in elements
+    constexpr int PITCH = KCB + 16;  // LDS row pitch in bytes (pixel rows and weight rows)
+    constexpr int NT = NFRAG * 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, g = lane >> 4;
+
+    int bid = blockIdx.x;
+    const int txi = bid % p.ntile[2]; bid /= p.ntile[2];
+    const int tyi = bid % p.ntile[1]; bid /= p.ntile[1];
+    const int tzi = bid % p.ntile[0];
+    const int img = bid / p.ntile[0];
+    const int slot = blockIdx.x % MI_NSLOT;
+    const int n0 = blockIdx.y * NT;
+    const int ph = blockIdx.z;
+    const int bz0 = tzi << p.tlog[0], by0 = tyi << p.tlog[1], bx0 = txi << p.tlog[2];
+    const int PP = p.pd[0] * p.pd[1] * p.pd[2];
+    char* smA = smem;
+    char* smW = smem + PP * PITCH;
+
+    const int mx = (1 << p.tlog[2]) - 1, my = (1 << p.tlog[1]) - 1;
+    int a_base[4];
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf) {
+        const int pidx = wave * 64 + mf * 16 + lr;
+        const int tx = pidx & mx, ty = (pidx >> p.tlog[2]) & my, tz = pidx >> (p.tlog[2] + p.tlog[1]);
+        a_base[mf] = (((tz * p.sa) * p.pd[1] + ty * p.sa) * p.pd[2] + tx * p.sa) * PITCH;
+    }
+    const int t_begin = p.phase_start[ph], t_end = p.phase_start[ph + 1];
+    const int iz0 = bz0 * p.sa + p.omin[0], iy0 = by0 * p.sa + p.omin[1], ix0 = bx0 * p.sa + p.omin[2];
+    const int pd12 = p.pd[1] * p.pd[2];
+
+    v4f acc[4][NFRAG];
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NFRAG; ++nf) acc[mf][nf] = v4f{0.f, 0.f, 0.f, 0.f};
+
+    for (int kc = 0; kc < p.K; kc += KCE) {
+        const char* src;
+        int spitch, scoff;
+        if (kc < p.in0_c) { src = p.in0; spitch = p.in0_pitch; scoff = p.in0_coff + kc; }
+        else { src = p.in1; spitch = p.in1_pitch; scoff = p.in1_coff + kc - p.in0_c; }
+        for (int tg = t_begin; tg < t_end; tg += p.tapg) {
+            const int ntg = min(p.tapg, t_end - tg);
+            __syncthreads();
+            if (tg == t_begin) {
+                // stage the input patch of this contraction chunk (zero outside the tensor)
+                for (int id = tid; id < PP * CPS; id += 256) {
+                    const int pix = id / CPS, cc = id % CPS;
+                    const int pz = pix / pd12; const int r = pix - pz * pd12;
+                    const int py = r / p.pd[2]; const int px = r - py * p.pd[2];
+                    const int iz = iz0 + pz, iy = iy0 + py, ix = ix0 + px;
+                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                    if ((unsigned)iz < (unsigned)p.id[0] && (unsigned)iy < (unsigned)p.id[1] &&
+                        (unsigned)ix < (unsigned)p.id[2]) {
+                        const size_t gp = ((size_t)(img * p.id[0] + iz) * p.id[1] + iy) * p.id[2] + ix;
+                        v = *reinterpret_cast<const uint4*>(src + (gp * spitch + scoff) * ESZ + cc * 16);
+                    }
+                    *reinterpret_cast<uint4*>(smA + pix * PITCH + cc * 16) = v;
+                }
+            }
+            // stage the weight tile: rows (tap, channel slot), this chunk's KCB bytes
+            const int ntg_pad = (CPS == 2) ? ((ntg + 1) & ~1) : ntg;
+            for (int id = tid; id < ntg_pad * NT * CPS; id += 256) {
+                const int cc = id % CPS; const int row = id / CPS;
+                const int r = row % NT; const int tl = row / NT;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (tl < ntg) {
+                    const int n = n0 + chan_of_row<NFRAG>(r >> 4, r & 15);
+                    v = *reinterpret_cast<const uint4*>(p.w + (((size_t)(tg + tl) * p.N + n) * p.K + kc) * ESZ + cc * 16);
+                }
+                *reinterpret_cast<uint4*>(smW + row * PITCH + cc * 16) = v;
+            }
+            __syncthreads();
+            const int nsteps = (CPS == 4) ? ntg : (ntg + 1) / 2;
+            for (int s = 0; s < nsteps; ++s) {
+                int tl, cc, toff;
+                if (CPS == 4) {
+                    tl = s; cc = g;
+                    toff = p.tap_off[tg + s] * PITCH;
+                } else {
+                    tl = 2 * s + (g >> 1); cc = g & 1;
+                    const int o0 = p.tap_off[tg + 2 * s];
+                    const int o1 = p.tap_off[tg + min(2 * s + 1, ntg - 1)];
+                    toff = ((g >> 1) ? o1 : o0) * PITCH;
+                }
+                uint4 bfr[4], afr[NFRAG];
+#pragma unroll
+                for (int mf = 0; mf < 4; ++mf)
+                    bfr[mf] = *reinterpret_cast<const uint4*>(smA + a_base[mf] + toff + cc * 16);
+#pragma unroll
+                for (int nf = 0; nf < NFRAG; ++nf)
+                    afr[nf] = *reinterpret_cast<const uint4*>(smW + ((tl * NT + nf * 16 + lr) * PITCH) + cc * 16);
+#pragma unroll
+                for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+                    for (int nf = 0; nf < NFRAG; ++nf) acc[mf][nf] = mma16<TR>(afr[nf], bfr[mf], acc[mf][nf]);
+            }
+        }
+    }
+
+    // ---- epilogue: statistics, bias, addend, store -----------------------------
+    const bool do_stats = p.stats != nullptr;
+    float s1[NFRAG][4], s2[NFRAG][4];
+#pragma unroll
+    for (int nf = 0; nf < NFRAG; ++nf)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s1[nf][j] = 0.f; s2[nf][j] = 0.f; }
+
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf) {
+        const int pidx = wave * 64 + mf * 16 + lr;
+        const int tx = pidx & mx, ty = (pidx >> p.tlog[2]) & my, tz = pidx >> (p.tlog[2] + p.tlog[1]);
+        const int bz = bz0 + tz, by = by0 + ty, bx = bx0 + tx;
+        const bool valid = bz < p.bd[0] && by < p.bd[1] && bx < p.bd[2];
+        if (do_stats) {
+#pragma unroll
+            for (int nf = 0; nf < NFRAG; ++nf)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = valid ? acc[mf][nf][j] : 0.f;
+                    s1[nf][j] += v; s2[nf][j] += v * v;
+                }
+        }
+        if (valid) {
+            const int oz = bz * p.so + p.phase_off[ph][0], oy = by * p.so + p.phase_off[ph][1],
+                      ox = bx * p.so + p.phase_off[ph][2];
+            const size_t op = ((size_t)(img * p.od[0] + oz) * p.od[1] + oy) * p.od[2] + ox;
+            if (NFRAG == 1) {
+                const int ch = n0 + 4 * g;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[mf][0][j];
+                if (p.bias && ch >= p.bias_c0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += p.bias[ch - p.bias_c0 + j];
+                }
+                if (p.addend) {
+                    float a[4];
+                    load_n<TR, 4>(p.addend + (op * p.add_pitch + p.add_coff + ch) * ESZ, a);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += a[j];
+                }
+                store_n<TR, 4>(p.out + (op * p.out_pitch + p.out_coff + ch) * ESZ, v);
+            } else {
+#pragma unroll
+                for (int pf = 0; pf < NFRAG / 2; ++pf) {
+                    const int ch = n0 + 32 * pf + 8 * g;
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[j] = acc[mf][2 * pf][j]; v[4 + j] = acc[mf][2 * pf + 1][j]; }
+                    if (p.bias && ch >= p.bias_c0) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] += p.bias[ch - p.bias_c0 + j];
+                    }
+                    if (p.addend) {
+                        float a[8];
+                        load_n<TR, 8>(p.addend + (op * p.add_pitch + p.add_coff + ch) * ESZ, a);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] += a[j];
+                    }
+                    store_n<TR, 8>(p.out + (op * p.out_pitch + p.out_coff + ch) * ESZ, v);
+                }
+            }
+        }
+    }
+    if (do_stats) {
+        __syncthreads();
+        float* sst = reinterpret_cast<float*>(smem);  // [NT][2]
+        for (int i = tid; i < NT * 2; i += 256) sst[i] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int nf = 0; nf < NFRAG; ++nf)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float a = s1[nf][j], b = s2[nf][j];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+                if (lr == 0) {
+                    const int cl = chan_of_row<NFRAG>(nf, 4 * g + j);
+                    atomicAdd(&sst[cl * 2], a);
+                    atomicAdd(&sst[cl * 2 + 1], b);
+                }
+            }
+        __syncthreads();
+        for (int i = tid; i < NT * 2; i += 256) {
+            const int ch = n0 + (i >> 1);
+            if (ch < p.nstat)
+                atomicAdd(&p.stats[(((size_t)img * MI_NSLOT + slot) * p.stats_c + ch) * 2 + (i & 1)], sst[i]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// weight gradient
+// ---------------------------------------------------------------------------------
+// Workgroup = 4 waves arranged WK x WF x WS: WF x WS waves tile the (F, S) channel block,
+// WK waves split the pixels (contraction) of each staged tile.  Every wave owns
+// FF x SF 16x16 fragments for each of the NT taps.
+template <class TR, int NT, int FF, int SF, int WF, int WS>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
+    constexpr int ESZ = TR::ESZ;
+    constexpr int WK = 4 / (WF * WS);
+    constexpr int FB = 16 * FF * WF, SB = 16 * SF * WS;
+    constexpr int FPITCH = FB * ESZ + 16, SPITCH = SB * ESZ + 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, g = lane >> 4;
+    const int ws = wave % WS, wf = (wave / WS) % WF, wk = wave / (WS * WF);
+    const int fb0 = blockIdx.y * FB;
+    const int sblk = blockIdx.z / p.ntapg, tgi = blockIdx.z % p.ntapg;
+    const int sb0 = sblk * SB;
+    const int PP = p.pd[0] * p.pd[1] * p.pd[2];
+    const int pd12 = p.pd[1] * p.pd[2];
+    char* smF = smem;
+    char* smS = smem + 256 * FPITCH;
+    const int mx = (1 << p.tlog[2]) - 1, my = (1 << p.tlog[1]) - 1;
+
+    v4f acc[NT][FF][SF];
+    v4f accb[FF];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int a = 0; a < FF; ++a)
+#pragma unroll
+            for (int b = 0; b < SF; ++b) acc[t][a][b] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < FF; ++a) accb[a] = v4f{0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = (ws == 0) && (blockIdx.z == 0);
+
+    const char* fsrc; int fpitch, fcoff;
+    if (fb0 < p.f0_c) { fsrc = p.f0; fpitch = p.f0_pitch; fcoff = p.f0_coff + fb0; }
+    else { fsrc = p.f1; fpitch = p.f1_pitch; fcoff = p.f1_coff + fb0 - p.f0_c; }
+    const int tiles_per_img = p.ntile[0] * p.ntile[1] * p.ntile[2];
+
+    for (int tile = blockIdx.x; tile < p.tiles_total; tile += p.nsplit) {
+        const int img = tile / tiles_per_img;
+        int tr = tile - img * tiles_per_img;
+        const int txi = tr % p.ntile[2]; tr /= p.ntile[2];
+        const int tyi = tr % p.ntile[1]; const int tzi = tr / p.ntile[1];
+        const int bz0 = tzi << p.tlog[0], by0 = tyi << p.tlog[1], bx0 = txi << p.tlog[2];
+        const int iz0 = bz0 * p.ss + p.omin[0] + p.tg_zoff[tgi], iy0 = by0 * p.ss + p.omin[1],
+                  ix0 = bx0 * p.ss + p.omin[2];
+        __syncthreads();
+        // F tile: 256 base pixels x FB channels
+        {
+            constexpr int VPP = FB * ESZ / 16;  // 16-byte vectors per pixel
+            for (int id = tid; id < 256 * VPP; id += 256) {
+                const int pix = id / VPP, cv = id % VPP;
+                const int tx = pix & mx, ty = (pix >> p.tlog[2]) & my, tz = pix >> (p.tlog[2] + p.tlog[1]);
+                const int bz = bz0 + tz, by = by0 + ty, bx = bx0 + tx;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (bz < p.bd[0] && by < p.bd[1] && bx < p.bd[2]) {
+                    const size_t gp = ((size_t)(img * p.bd[0] + bz) * p.bd[1] + by) * p.bd[2] + bx;
+                    v = *reinterpret_cast<const uint4*>(fsrc + (gp * fpitch + fcoff) * ESZ + cv * 16);
+                }
+                *reinterpret_cast<uint4*>(smF + pix * FPITCH + cv * 16) = v;
+            }
+        }
+        // S patch
+        {
+            constexpr int VPP = SB * ESZ / 16;
+            for (int id = tid; id < PP * VPP; id += 256) {
+                const int pix = id / VPP, cv = id % VPP;
+                const int pz = pix / pd12; const int r = pix - pz * pd12;
+                const int py = r / p.pd[2]; const int px = r - py * p.pd[2];
+                const int iz = iz0 + pz, iy = iy0 + py, ix = ix0 + px;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if ((unsigned)iz < (unsigned)p.sd[0] && (unsigned)iy < (unsigned)p.sd[1] &&
+                    (unsigned)ix < (unsigned)p.sd[2]) {
+                    const size_t gp = ((size_t)(img * p.sd[0] + iz) * p.sd[1] + iy) * p.sd[2] + ix;
+                    v = *reinterpret_cast<const uint4*>(p.s + (gp * p.s_pitch + p.s_coff + sb0) * ESZ + cv * 16);
+                }
+                *reinterpret_cast<uint4*>(smS + pix * SPITCH + cv * 16) = v;
+            }
+        }
+        __syncthreads();
+        for (int ks = wk; ks < 8; ks += WK) {
+            if (TR::ESZ == 2) {
+                // bf16: K-step = 32 pixels; lane group g covers pixels 8g..8g+7 via two transposed LDS reads
+                const int q = lr >> 2, pp = lr & 3;
+                int soff[2];
+                uint4 afr[FF];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int pix = ks * 32 + 8 * g + 4 * h + q;
+                    const int tx = pix & mx, ty = (pix >> p.tlog[2]) & my, tz = pix >> (p.tlog[2] + p.tlog[1]);
+                    soff[h] = (((tz * p.ss) * p.pd[1] + ty * p.ss) * p.pd[2] + tx * p.ss) * SPITCH + pp * 8;
+                }
+#pragma unroll
+                for (int a = 0; a < FF; ++a) {
+                    const int c0 = ((wf * FF + a) * 16 + pp * 4) * 2;
+                    const int p0 = ks * 32 + 8 * g + q;
+                    v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) v4s*)(smF + p0 * FPITCH + c0));
+                    v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) v4s*)(smF + (p0 + 4) * FPITCH + c0));
+                    v8s f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    afr[a] = __builtin_bit_cast(uint4, f);
+                }
+                if (do_bias) {
+                    const uint4 ones = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+#pragma unroll
+                    for (int a = 0; a < FF; ++a) accb[a] = mma16<BF16>(afr[a], ones, accb[a]);
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int toff = p.tap_off[t] * SPITCH;
+                    uint4 bfr[SF];
+#pragma unroll
+                    for (int b = 0; b < SF; ++b) {
+                        const int c0 = ((ws * SF + b) * 16) * 2;
+                        v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) v4s*)(smS + soff[0] + toff + c0));
+                        v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) v4s*)(smS + soff[1] + toff + c0));
+                        v8s f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        bfr[b] = __builtin_bit_cast(uint4, f);
+                    }
+#pragma unroll
+                    for (int a = 0; a < FF; ++a)
+#pragma unroll
+                        for (int b = 0; b < SF; ++b) acc[t][a][b] = mma16<BF16>(afr[a], bfr[b], acc[t][a][b]);
+                }
+            } else {
+                // fp32: eight 16x16x4 MFMAs per 32-pixel step; lane (row lr, k-slot g) reads pixel 4i+g
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int pix = ks * 32 + 4 * i + g;
+                    const int tx = pix & mx, ty = (pix >> p.tlog[2]) & my, tz = pix >> (p.tlog[2] + p.tlog[1]);
+                    const int soff = (((tz * p.ss) * p.pd[1] + ty * p.ss) * p.pd[2] + tx * p.ss) * SPITCH;
+                    float av[FF];
+#pragma unroll
+                    for (int a = 0; a < FF; ++a)
+                        av[a] = *reinterpret_cast<const float*>(smF + pix * FPITCH + ((wf * FF + a) * 16 + lr) * 4);
+                    if (do_bias) {
+#pragma unroll
+                        for (int a = 0; a < FF; ++a)
+                            accb[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], 1.0f, accb[a], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int toff = p.tap_off[t] * SPITCH;
+#pragma unroll
+                        for (int b = 0; b < SF; ++b) {
+                            const float bv =
+                                *reinterpret_cast<const float*>(smS + soff + toff + ((ws * SF + b) * 16 + lr) * 4);
+#pragma unroll
+                            for (int a = 0; a < FF; ++a)
+                                acc[t][a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv, acc[t][a][b], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // ---- write this wave's slab ---------------------------------------------------
+    const size_t slab = (size_t)blockIdx.x * WK + wk;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const size_t tbase = (slab * p.ntaps_total + (size_t)tgi * NT + t) * p.F;
+#pragma unroll
+        for (int a = 0; a < FF; ++a)
+#pragma unroll
+            for (int b = 0; b < SF; ++b)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int f = fb0 + (wf * FF + a) * 16 + 4 * g + j;
+                    const int s = sb0 + (ws * SF + b) * 16 + lr;
+                    p.partial[(tbase + f) * p.S + s] = acc[t][a][b][j];
+                }
+    }
+    if (do_bias && lr == 0) {
+#pragma unroll
+        for (int a = 0; a < FF; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                p.partial_bias[slab * p.F + fb0 + (wf * FF + a) * 16 + 4 * g + j] = accb[a][j];
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// slab reduction and weight packing (descriptor tables in device memory)
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void reduce_body(const ReduceDesc& d);
+template <class TR>
+__device__ __forceinline__ void pack_body(const PackDesc& d);
+__global__ __launch_bounds__(256) void reduce_kernel(const ReduceDesc* __restrict__ descs) {
+    const ReduceDesc d = descs[blockIdx.y];
+    reduce_body(d);
+}
+template <class TR>
+__global__ __launch_bounds__(256) void pack_kernel(const PackDesc* __restrict__ descs) {
+    const PackDesc d = descs[blockIdx.y];
+    pack_body<TR>(d);
+}
+
+__device__ __forceinline__ void reduce_body(const ReduceDesc& d) {
+    const int nw = d.ntaps * d.Fcnt * d.S;
+    const int total = nw + (d.dst_b ? d.Fcnt : 0);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        if (i < nw) {
+            const int s = i % d.S; const int r = i / d.S;
+            const int f = r % d.Fcnt; const int t = r / d.Fcnt;
+            float a = 0.f;
+            const size_t stride = (size_t)d.ntaps * d.Ftot * d.S;
+            const size_t off = ((size_t)t * d.Ftot + d.f_off + f) * d.S + s;
+            for (int sl = 0; sl < d.nslab; ++sl) a += d.partial[sl * stride + off];
+            d.dst_w[((size_t)f * d.S + s) * d.KK + d.kidx[t]] = a;
+        } else {
+            const int f = i - nw;
+            float a = 0.f;
+            for (int sl = 0; sl < d.nslab; ++sl) a += d.partial_bias[(size_t)sl * d.Ftot + d.f_off + f];
+            d.dst_b[f] = a;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void reduce_one_kernel(const ReduceDesc d) { reduce_body(d); }
+
+template <class TR>
+__device__ __forceinline__ void pack_body(const PackDesc& d) {
+    const int total = d.ntaps * d.N * d.K;
+    typename TR::elem* dst = reinterpret_cast<typename TR::elem*>(d.dst);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int k = i % d.K; const int r = i / d.K;
+        const int n = r % d.N; const int t = r / d.N;
+        const float v = d.src[(size_t)n * d.sn + (size_t)k * d.sk + d.kidx[t]];
+        const size_t o = ((size_t)t * d.Ntot + d.n_off + n) * d.Ktot + d.k_off + k;
+        if (TR::ESZ == 2) dst[o] = f32_to_bf16(v);
+        else reinterpret_cast<float*>(dst)[o] = v;
+    }
+}
+template <class TR>
+__global__ __launch_bounds__(256) void pack_one_kernel(const PackDesc d) { pack_body<TR>(d); }
+
+template <class K>
+int set_lds(K kern, size_t bytes) {
+    if (bytes > 160 * 1024) { mi_set_error("LDS request exceeds 160 KiB"); return -1; }
+    if (bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) { mi_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return -2; }
+    }
+    return 0;
+}
+
+template <class TR, int CPS, int NFRAG>
+int launch_igemm_t(const IgemmParams& p, hipStream_t st) {
+    constexpr int PITCH = CPS * 16 + 16;
+    const int PP = p.pd[0] * p.pd[1] * p.pd[2];
+    const int tapg_pad = (CPS == 2) ? ((p.tapg + 1) & ~1) : p.tapg;
+    size_t lds = (size_t)PP * PITCH + (size_t)tapg_pad * NFRAG * 16 * PITCH;
+    if (lds < (size_t)NFRAG * 16 * 2 * 4) lds = NFRAG * 16 * 2 * 4;
+    auto kern = igemm_kernel<TR, CPS, NFRAG>;
+    if (int r = set_lds(kern, lds)) return r;
+    dim3 grid(p.nb * p.ntile[0] * p.ntile[1] * p.ntile[2], p.N / (NFRAG * 16), p.nphase);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { mi_set_error(std::string("igemm launch: ") + hipGetErrorString(e)); return -2; }
+    return 0;
+}
+
+template <class TR, int NT, int FF, int SF, int WF, int WS>
+int launch_wgrad_t(const WgradParams& p, hipStream_t st) {
+    constexpr int FB = 16 * FF * WF, SB = 16 * SF * WS;
+    constexpr int FPITCH = FB * TR::ESZ + 16, SPITCH = SB * TR::ESZ + 16;
+    const int PP = p.pd[0] * p.pd[1] * p.pd[2];
+    size_t lds = (size_t)256 * FPITCH + (size_t)PP * SPITCH;
+    auto kern = wgrad_kernel<TR, NT, FF, SF, WF, WS>;
+    if (int r = set_lds(kern, lds)) return r;
+    dim3 grid(p.nsplit, p.F / FB, (p.S / SB) * p.ntapg);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { mi_set_error(std::string("wgrad launch: ") + hipGetErrorString(e)); return -2; }
+    return 0;
+}
+
+}  // namespace
+
+static const size_t kLdsBudget = 150 * 1024;
+
+static size_t igemm_lds_for(const IgemmParams& p, int cps, int nfrag) {
+    const int PITCH = cps * 16 + 16;
+    const int PP = p.pd[0] * p.pd[1] * p.pd[2];
+    const int tapg_pad = (cps == 2) ? ((p.tapg + 1) & ~1) : p.tapg;
+    return (size_t)PP * PITCH + (size_t)tapg_pad * nfrag * 16 * PITCH;
+}
+
+// Chooses the contraction chunk (CPS 16-byte pieces per pixel per stage) and the N tile
+// (NFRAG 16-channel fragments) so that the LDS images fit.
+void igemm_config(int dtype, const IgemmParams& p, int* cps, int* nfrag) {
+    const int esz = dtype ? 2 : 4;
+    const int kce4 = 64 / esz;
+    int c = (p.K % kce4 == 0 && (p.in0_c >= p.K || p.in0_c % kce4 == 0)) ? 4 : 2;
+    int nf = (p.N % 64 == 0) ? 4 : (p.N % 32 == 0) ? 2 : 1;
+    if (c == 4 && igemm_lds_for(p, c, nf) > kLdsBudget) c = 2;
+    while (nf > 1 && igemm_lds_for(p, c, nf) > kLdsBudget) nf >>= 1;
+    *cps = c; *nfrag = nf;
+}
+
+size_t igemm_lds_bytes(int dtype, const IgemmParams& p) {
+    int cps, nfrag;
+    igemm_config(dtype, p, &cps, &nfrag);
+    return igemm_lds_for(p, cps, nfrag);
+}
+
+int launch_igemm(int dtype, const IgemmParams& p, hipStream_t st) {
+    int cps, nfrag;
+    igemm_config(dtype, p, &cps, &nfrag);
+    const int esz = dtype ? 2 : 4;
+    MI_CHECK(p.K % (32 / esz) == 0, "contraction channels must be a multiple of 32 bytes");
+    MI_CHECK(p.in0_c >= p.K || p.in0_c % (32 / esz) == 0, "first-source channel count must be a multiple of 32 bytes");
+    MI_CHECK(p.N % 16 == 0, "output channels must be a multiple of 16");
+    MI_CHECK(p.tlog[0] + p.tlog[1] + p.tlog[2] == 8, "tile must hold 256 base pixels");
+    MI_CHECK(p.tapg >= 1 && p.tapg <= 9, "tap group size");
+    MI_CHECK(igemm_lds_for(p, cps, nfrag) <= 160 * 1024, "LDS images do not fit");
+#define IG_CASE(TRT, C, NF) \
+    if (cps == C && nfrag == NF) return launch_igemm_t<TRT, C, NF>(p, st);
+    if (dtype) {
+        IG_CASE(BF16, 4, 4) IG_CASE(BF16, 4, 2) IG_CASE(BF16, 4, 1)
+        IG_CASE(BF16, 2, 4) IG_CASE(BF16, 2, 2) IG_CASE(BF16, 2, 1)
+    } else {
+        IG_CASE(F32, 4, 4) IG_CASE(F32, 4, 2) IG_CASE(F32, 4, 1)
+        IG_CASE(F32, 2, 4) IG_CASE(F32, 2, 2) IG_CASE(F32, 2, 1)
+    }
+#undef IG_CASE
+    mi_set_error("launch_igemm: no kernel variant");
+    return -1;
+}
+
+static size_t wgrad_lds_for(int dtype, const WgradParams& p, int FB, int SB) {
+    const int esz = dtype ? 2 : 4;
+    const int PP = p.pd[0] * p.pd[1] * p.pd[2];
+    return (size_t)256 * (FB * esz + 16) + (size_t)PP * (SB * esz + 16);
+}
+
+// Weight-gradient block shape: FB x SB channels per workgroup (fragments per wave and wave
+// arrangement follow), shrunk until the LDS images fit.
+void wgrad_config(int dtype, const WgradParams& p, int* ff, int* sf, int* wf, int* wsn) {
+    auto pick = [](int c, int maxblk) { int b = maxblk; while (b > 16 && c % b) b >>= 1; return b; };
+    const int maxb = dtype ? 64 : 32;
+    int FB = pick(p.F, maxb), SB = pick(p.S, maxb);
+    if (p.f0_c < p.F) while (FB > 16 && p.f0_c % FB) FB >>= 1;
+    while (wgrad_lds_for(dtype, p, FB, SB) > kLdsBudget && (SB > 16 || FB > 16)) {
+        if (SB > 16 && SB >= FB) SB >>= 1; else if (FB > 16) FB >>= 1; else SB >>= 1;
+    }
+    *ff = FB >= 32 ? 2 : 1; *wf = FB / (16 * *ff);
+    *sf = SB >= 32 ? 2 : 1; *wsn = SB / (16 * *sf);
+}
+
+int wgrad_slabs(int dtype, const WgradParams& p) {
+    int ff, sf, wf, wsn;
+    wgrad_config(dtype, p, &ff, &sf, &wf, &wsn);
+    return p.nsplit * (4 / (wf * wsn));
+}
+
+size_t wgrad_lds_bytes(int dtype, const WgradParams& p) {
+    int ff, sf, wf, wsn;
+    wgrad_config(dtype, p, &ff, &sf, &wf, &wsn);
+    return wgrad_lds_for(dtype, p, 16 * ff * wf, 16 * sf * wsn);
+}
+
+int launch_wgrad(int dtype, const WgradParams& p, hipStream_t st) {
+    int ff, sf, wf, wsn;
+    wgrad_config(dtype, p, &ff, &sf, &wf, &wsn);
+    MI_CHECK(p.F % 16 == 0 && p.S % 16 == 0, "channel counts must be multiples of 16");
+    MI_CHECK(p.f0_c >= p.F || p.f0_c % (16 * ff * wf) == 0, "first-source channel count must be a multiple of the F block");
+    MI_CHECK(p.tlog[0] + p.tlog[1] + p.tlog[2] == 8, "tile must hold 256 base pixels");
+    MI_CHECK(wgrad_lds_for(dtype, p, 16 * ff * wf, 16 * sf * wsn) <= 160 * 1024, "LDS images do not fit");
+    const int nt = p.ntaps_total / p.ntapg;
+    MI_CHECK(nt == 9 || nt == 1, "taps per group must be 9 or 1");
+#define WG_CASE(TRT, NTT, A, B, C, D) \
+    if (nt == NTT && ff == A && sf == B && wf == C && wsn == D) return launch_wgrad_t<TRT, NTT, A, B, C, D>(p, st);
+#define WG_ALL(TRT, NTT)                                                                  \
+    WG_CASE(TRT, NTT, 1, 1, 1, 1) WG_CASE(TRT, NTT, 2, 1, 1, 1) WG_CASE(TRT, NTT, 1, 2, 1, 1) \
+    WG_CASE(TRT, NTT, 2, 2, 1, 1) WG_CASE(TRT, NTT, 2, 1, 2, 1) WG_CASE(TRT, NTT, 1, 2, 1, 2) \
+    WG_CASE(TRT, NTT, 2, 2, 2, 1) WG_CASE(TRT, NTT, 2, 2, 1, 2) WG_CASE(TRT, NTT, 2, 2, 2, 2)
+    if (dtype) { WG_ALL(BF16, 9) WG_ALL(BF16, 1) }
+    else { WG_ALL(F32, 9) WG_ALL(F32, 1) }
+#undef WG_ALL
+#undef WG_CASE
+    mi_set_error("launch_wgrad: no kernel variant");
+    return -1;
+}
+
+int launch_reduce(const ReduceDesc* d_descs, int ndesc, int max_elems, hipStream_t st) {
+    if (ndesc <= 0) return 0;
+    int gx = (max_elems + 255) / 256;
+    if (gx > 64) gx = 64;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(reduce_kernel, dim3(gx, ndesc), dim3(256), 0, st, d_descs);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { mi_set_error(std::string("reduce launch: ") + hipGetErrorString(e)); return -2; }
+    return 0;
+}
+
+int launch_pack(int dtype, const PackDesc* d_descs, int ndesc, int max_elems, hipStream_t st) {
+    if (ndesc <= 0) return 0;
+    int gx = (max_elems + 255) / 256;
+    if (gx > 64) gx = 64;
+    if (gx < 1) gx = 1;
+    if (dtype) hipLaunchKernelGGL(pack_kernel<BF16>, dim3(gx, ndesc), dim3(256), 0, st, d_descs);
+    else hipLaunchKernelGGL(pack_kernel<F32>, dim3(gx, ndesc), dim3(256), 0, st, d_descs);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { mi_set_error(std::string("pack launch: ") + hipGetErrorString(e)); return -2; }
+    return 0;
+}
+
+int launch_reduce_one(const ReduceDesc& d, hipStream_t st) {
+    int total = d.ntaps * d.Fcnt * d.S + d.Fcnt;
+    int gx = (total + 255) / 256; if (gx > 64) gx = 64; if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(reduce_one_kernel, dim3(gx), dim3(256), 0, st, d);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { mi_set_error(std::string("reduce launch: ") + hipGetErrorString(e)); return -2; }
+    return 0;
+}
+
+int launch_pack_one(int dtype, const PackDesc& d, hipStream_t st) {
+    int total = d.ntaps * d.N * d.K;
+    int gx = (total + 255) / 256; if (gx > 256) gx = 256; if (gx < 1) gx = 1;
+    if (dtype) hipLaunchKernelGGL(pack_one_kernel<BF16>, dim3(gx), dim3(256), 0, st, d);
+    else hipLaunchKernelGGL(pack_one_kernel<F32>, dim3(gx), dim3(256), 0, st, d);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { mi_set_error(std::string("pack launch: ") + hipGetErrorString(e)); return -2; }
+    return 0;
+}

@@ -1,0 +1,134 @@
+// Kernel parameter blocks (passed by value as kernel arguments) and launcher prototypes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#define MI_MAX_TAPS 27
+#define MI_MAX_PHASE 8
+
+// Gather-GEMM ("implicit GEMM") forward / dgrad launch.
+//   out[opix(b)][n] = sum_{t in taps(phase)} sum_k A[ipix(b,t)][k] * W[t][n][k]   (+bias, +addend)
+// b runs over a "base grid"; ipix(b,t) = b*sa + off_t (zero outside the tensor),
+// opix(b) = b*so + phase_off.  Convolution: sa=stride, so=1, one phase.  Transposed
+// convolution (and the data gradient of a strided convolution): sa=1, so=2, 2^ndim phases.
+struct IgemmParams {
+    const char* in0; const char* in1;       // contraction channels [0,in0_c) come from in0, the rest from in1
+    int in0_pitch, in0_coff, in0_c, in1_pitch, in1_coff;
+    int K;                                  // contraction channels in total
+    const char* w;                          // packed weights [tap][N][K], storage type of the activations
+    const float* bias; int bias_c0;         // bias[ch-bias_c0] is added to output channels >= bias_c0 (null: none)
+    char* out; int out_pitch, out_coff, N;
+    const char* addend; int add_pitch, add_coff;  // optional tensor added in the epilogue (may alias out)
+    float* stats; int stats_c, nstat;       // per-(image,slot,channel) {sum, sum of squares} of the first nstat channels
+    int nb;
+    int id[3], od[3], bd[3];                // gathered-tensor dims, output dims, base-grid dims (z,y,x)
+    int sa, so;
+    int tlog[3];                            // log2 of the tile dims; tile = 256 base pixels
+    int ntile[3];
+    int pd[3];                              // LDS patch dims (pixels)
+    int omin[3];                            // smallest gather offset per dim
+    int nphase;
+    int phase_off[MI_MAX_PHASE][3];
+    int phase_start[MI_MAX_PHASE + 1];      // tap range of each phase in tap_off / w
+    int tap_off[MI_MAX_TAPS];               // LDS patch pixel offset of each tap
+    int tapg;                               // taps staged per weight tile (<= 9)
+};
+
+// Weight-gradient launch: partial[slab][tap][f][s] = sum_{base pixels of the slab}
+//   Fm[b][f] * Sm[b*ss + off_tap][s]; plus partial_bias[slab][f] = sum_b Fm[b][f].
+struct WgradParams {
+    const char* f0; const char* f1;         // "fixed" operand (at base pixels), channels [0,f0_c) from f0, rest from f1
+    int f0_pitch, f0_coff, f0_c, f1_pitch, f1_coff, F;
+    const char* s; int s_pitch, s_coff, S;  // "shifted" operand
+    int nb;
+    int bd[3], sd[3];
+    int ss;
+    int tlog[3], ntile[3], pd[3], omin[3];
+    int ntapg;                              // tap groups (3-D: one per kz plane)
+    int tg_zoff[3];                         // extra z offset of the patch origin per tap group
+    int tap_off[9];                         // LDS patch pixel offsets of the taps of one group
+    int ntaps_total;
+    float* partial; float* partial_bias;
+    int tiles_total, nsplit;
+};
+
+// Reduction of weight-gradient slabs into the state_dict layout:
+//   dst_w[(f*S + s)*KK + kidx[tap]] = sum_slab partial[slab][tap][f_off+f][s]
+struct ReduceDesc {
+    const float* partial; const float* partial_bias;
+    int nslab, ntaps, Ftot, S, f_off, Fcnt, KK;
+    int kidx[MI_MAX_TAPS];
+    float* dst_w; float* dst_b;             // dst_b may be null
+};
+
+// Weight packing: dst[((t*Ntot + n_off + n)*Ktot + k_off + k)] = src[n*sn + k*sk + kidx[t]]
+struct PackDesc {
+    const float* src; void* dst;
+    int N, K, ntaps, sn, sk, Ntot, Ktot, n_off, k_off;
+    int kidx[MI_MAX_TAPS];
+};
+
+// Instance-norm + PReLU (+dropout, +residual) launch
+struct NormParams {
+    const char* x; int x_pitch, x_coff;     // raw conv output
+    const char* dy; int dy_pitch, dy_coff;  // backward: gradient of the activated output
+    const char* res; int res_pitch, res_coff;  // forward: optional residual added after the activation
+    char* out; int out_pitch, out_coff;     // forward: activated output; backward: gradient of x
+    const float* stats;                     // forward statistics [nb][NSLOT][c][2]
+    float* bstats;                          // backward statistics [nb][NSLOT][c][2]
+    const float* alpha;                     // PReLU slope (device scalar)
+    float* dalpha;                          // gradient of the slope (device scalar, accumulated)
+    int nb, npix, c;
+    float eps;
+    unsigned long long seed; unsigned layer, drop_thresh; float drop_scale;  // drop_thresh==0: no dropout
+};
+
+
+// One-channel <-> N-channel stride-2 kernels (first encoder conv, last decoder transposed conv)
+// and the one-channel 3^d stencil (top conv_only residual unit).
+//   fine grid  : one-channel fp32 tensor [nb][fd0][fd1][fd2]
+//   coarse grid: N-channel channels-last tensor at fd/2
+struct C1Params {
+    const float* x1; float* x1_out;         // fine one-channel tensor (input / output)
+    const char* y; char* y_out;             // coarse N-channel tensor (input / output)
+    int y_pitch, y_coff, N;
+    const float* w; const float* w2; int n_w1;  // weights [n][KK]; channels >= n_w1 read w2[(n-n_w1)][KK]
+    const float* bias; int bias_c0;
+    float* stats; int stats_c, nstat;
+    int ndim, nb;
+    int fd[3], cd[3];
+    float* partial; float* partial_bias;    // weight-gradient slabs [slab][KK][N], [slab][N]
+    int nsplit;
+};
+struct StencilParams {
+    const float* in; const float* dout; float* out;
+    const float* w; const float* bias; const float* addend;
+    int flip, ndim, nb;
+    int d[3];
+    float* partial; float* partial_bias;    // [slab][KK], [slab]
+    int nsplit;
+};
+
+#ifdef __cplusplus
+extern "C++" {
+int launch_igemm(int dtype, const IgemmParams& p, hipStream_t st);
+int launch_wgrad(int dtype, const WgradParams& p, hipStream_t st);
+int launch_reduce(const ReduceDesc* d_descs, int ndesc, int max_elems, hipStream_t st);
+int launch_pack(int dtype, const PackDesc* d_descs, int ndesc, int max_elems, hipStream_t st);
+int launch_reduce_one(const ReduceDesc& d, hipStream_t st);
+int launch_pack_one(int dtype, const PackDesc& d, hipStream_t st);
+int launch_norm_fwd(int dtype, const NormParams& p, hipStream_t st);
+int launch_norm_bwd(int dtype, const NormParams& p, hipStream_t st);
+int launch_c1_s2_fwd(int dtype, const C1Params& p, hipStream_t st);
+int launch_c1_s2_T(int dtype, const C1Params& p, hipStream_t st);
+int launch_c1_s2_wgrad(int dtype, const C1Params& p, hipStream_t st);
+int launch_stencil(const StencilParams& p, hipStream_t st);
+int launch_stencil_wgrad(const StencilParams& p, hipStream_t st);
+void igemm_config(int dtype, const IgemmParams& p, int* cps, int* nfrag);
+size_t igemm_lds_bytes(int dtype, const IgemmParams& p);
+void wgrad_config(int dtype, const WgradParams& p, int* ff, int* sf, int* wf, int* wsn);
+int wgrad_slabs(int dtype, const WgradParams& p);
+size_t wgrad_lds_bytes(int dtype, const WgradParams& p);
+}
+#endif

@@ -1,0 +1,272 @@
+// Reductions and element-wise kernels around the network: sigmoid-Dice(+BCE) loss forward /
+// backward, hard-Dice confusion counts, AdamW over a flat parameter buffer, sliding-window
+// crop / blend, and small utilities.  All HBM-bound; 16-byte accesses where the layout allows.
+#include "common.h"
+#include "kparams.h"
+#include "lossparams.h"
+
+namespace {
+
+__device__ __forceinline__ float load_label(const void* t, int tdtype, size_t i, int fold2) {
+    float v;
+    switch (tdtype) {
+        case 1: v = (float)reinterpret_cast<const unsigned char*>(t)[i]; break;
+        case 2: v = (float)reinterpret_cast<const long long*>(t)[i]; break;
+        case 3: v = (float)reinterpret_cast<const int*>(t)[i]; break;
+        default: v = reinterpret_cast<const float*>(t)[i]; break;
+    }
+    if (fold2 && v == 2.0f) v = 1.0f;
+    return v;
+}
+
+// sums[b] = { sum p*t, sum p, sum t, sum bce }  with p = sigmoid(z)
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const LossParams p) {
+    __shared__ float red[4][4];
+    const int b = blockIdx.y;
+    const float* z = p.logits + (size_t)b * p.npix;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < p.npix; i += gridDim.x * 256) {
+        const float zi = z[i];
+        const float t = load_label(p.target, p.tdtype, (size_t)b * p.npix + i, p.fold2);
+        const float e = __expf(-fabsf(zi));
+        const float s = zi >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+        a0 += s * t; a1 += s; a2 += t;
+        a3 += fmaxf(zi, 0.f) - zi * t + log1pf(e);
+    }
+    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][w] = a0; red[1][w] = a1; red[2][w] = a2; red[3][w] = a3; }
+    __syncthreads();
+    if (threadIdx.x < 4)
+        atomicAdd(&p.sums[b * 4 + threadIdx.x],
+                  red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+// loss = lambda_dice * mean_b(1 - (2I+snr)/(P+T+sdr)) + lambda_ce * sum_b(bce) / (nb*npix)
+__global__ void loss_finalize_kernel(const LossParams p) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float dice = 0.f, ce = 0.f;
+    for (int b = 0; b < p.nb; ++b) {
+        const float* s = p.sums + b * 4;
+        dice += 1.f - (2.f * s[0] + p.smooth_nr) / (s[1] + s[2] + p.smooth_dr);
+        ce += s[3];
+    }
+    const float l = p.lambda_dice * dice / (float)p.nb + p.lambda_ce * ce / ((float)p.nb * (float)p.npix);
+    p.loss[0] = l;
+    if (p.loss_accum) p.loss_accum[0] += l;
+}
+
+// dz = g * [ lambda_dice/nb * (-2 t D + (2I+snr)) / D^2 * s(1-s) + lambda_ce * (s - t)/(nb*npix) ],  D = P+T+sdr
+__global__ __launch_bounds__(256) void loss_bwd_kernel(const LossParams p) {
+    const int b = blockIdx.y;
+    const float* z = p.logits + (size_t)b * p.npix;
+    float* dz = p.dlogits + (size_t)b * p.npix;
+    const float g = (p.gout ? p.gout[0] : 1.f) * p.gscale;
+    const float* sm = p.sums + b * 4;
+    const float D = sm[1] + sm[2] + p.smooth_dr;
+    const float num = 2.f * sm[0] + p.smooth_nr;
+    const float cd = g * p.lambda_dice / ((float)p.nb * D * D);
+    const float cc = g * p.lambda_ce / ((float)p.nb * (float)p.npix);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < p.npix; i += gridDim.x * 256) {
+        const float zi = z[i];
+        const float t = load_label(p.target, p.tdtype, (size_t)b * p.npix + i, p.fold2);
+        const float e = __expf(-fabsf(zi));
+        const float s = zi >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+        dz[i] = cd * (num - 2.f * t * D) * s * (1.f - s) + cc * (s - t);
+    }
+}
+
+// counts[b] = { tp, fp, fn, tn } as 64-bit integers; prediction = (pred >= thresh), truth = (label == 1)
+__global__ __launch_bounds__(256) void dice_counts_kernel(const CountParams p) {
+    __shared__ unsigned red[4][4];
+    const int b = blockIdx.y;
+    const float* y = p.pred + (size_t)b * p.npix;
+    unsigned c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < p.npix; i += gridDim.x * 256) {
+        const bool pr = p.pred_is_binary ? (y[i] == 1.0f) : (y[i] >= p.thresh);
+        const bool gt = load_label(p.target, p.tdtype, (size_t)b * p.npix + i, p.fold2) == 1.0f;
+        c0 += pr && gt; c1 += pr && !gt; c2 += !pr && gt; c3 += !pr && !gt;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        c0 += __shfl_xor((int)c0, o, 64); c1 += __shfl_xor((int)c1, o, 64);
+        c2 += __shfl_xor((int)c2, o, 64); c3 += __shfl_xor((int)c3, o, 64);
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][w] = c0; red[1][w] = c1; red[2][w] = c2; red[3][w] = c3; }
+    __syncthreads();
+    if (threadIdx.x < 4)
+        atomicAdd(&p.counts[b * 4 + threadIdx.x],
+                  (unsigned long long)red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+// AdamW with decoupled weight decay over flat fp32 buffers (torch.optim.AdamW semantics,
+// amsgrad off): p *= 1 - lr*wd ; m,v update ; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ __launch_bounds__(256) void adamw_kernel(const AdamParams p) {
+    const long long n4 = p.n / 4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        float4 w = reinterpret_cast<float4*>(p.param)[i];
+        float4 g = reinterpret_cast<const float4*>(p.grad)[i];
+        float4 m = reinterpret_cast<float4*>(p.m)[i];
+        float4 v = reinterpret_cast<float4*>(p.v)[i];
+        float* wp = &w.x; float* gp = &g.x; float* mp = &m.x; float* vp = &v.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gg = gp[e] * p.gscale;
+            wp[e] *= p.decay;
+            mp[e] = p.beta1 * mp[e] + (1.f - p.beta1) * gg;
+            vp[e] = p.beta2 * vp[e] + (1.f - p.beta2) * gg * gg;
+            wp[e] -= p.step_size * mp[e] / (sqrtf(vp[e]) * p.inv_bc2_sqrt + p.eps);
+        }
+        reinterpret_cast<float4*>(p.param)[i] = w;
+        reinterpret_cast<float4*>(p.m)[i] = m;
+        reinterpret_cast<float4*>(p.v)[i] = v;
+    }
+    if (blockIdx.x == 0) {
+        for (long long i = n4 * 4 + threadIdx.x; i < p.n; i += 256) {
+            const float gg = p.grad[i] * p.gscale;
+            float w = p.param[i] * p.decay;
+            const float m = p.beta1 * p.m[i] + (1.f - p.beta1) * gg;
+            const float v = p.beta2 * p.v[i] + (1.f - p.beta2) * gg * gg;
+            w -= p.step_size * m / (sqrtf(v) * p.inv_bc2_sqrt + p.eps);
+            p.param[i] = w; p.m[i] = m; p.v[i] = v;
+        }
+    }
+}
+
+// windows[w][...] = padded image crop; one-channel fp32, any of 2-D / 3-D
+__global__ __launch_bounds__(256) void sw_gather_kernel(const SwParams p) {
+    const int w = blockIdx.y;  // window index among the launched group
+    const int gw = p.win0 + w;
+    const int b = gw / p.nwin, wi = gw % p.nwin;
+    const int rpix = p.roi[0] * p.roi[1] * p.roi[2];
+    const int* st = p.starts + wi * 3;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < rpix; i += gridDim.x * 256) {
+        const int x = i % p.roi[2]; const int r = i / p.roi[2];
+        const int y = r % p.roi[1]; const int z = r / p.roi[1];
+        // coordinates in the padded image -> original image (zero outside: constant padding, cval 0)
+        const int oz = st[0] + z - p.pad_lo[0], oy = st[1] + y - p.pad_lo[1], ox = st[2] + x - p.pad_lo[2];
+        float v = p.cval;
+        if ((unsigned)oz < (unsigned)p.img[0] && (unsigned)oy < (unsigned)p.img[1] && (unsigned)ox < (unsigned)p.img[2])
+            v = p.image[(((size_t)b * p.img[0] + oz) * p.img[1] + oy) * p.img[2] + ox];
+        p.windows[(size_t)w * rpix + i] = v;
+    }
+}
+
+// out[b][pixel] = (sum over the windows covering the pixel, in window order) / count
+__global__ __launch_bounds__(256) void sw_blend_kernel(const SwParams p) {
+    const int b = blockIdx.y;
+    const int ipix = p.img[0] * p.img[1] * p.img[2];
+    const int rpix = p.roi[0] * p.roi[1] * p.roi[2];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < ipix; i += gridDim.x * 256) {
+        const int x = i % p.img[2]; const int r = i / p.img[2];
+        const int y = r % p.img[1]; const int z = r / p.img[1];
+        const int pz = z + p.pad_lo[0], py = y + p.pad_lo[1], px = x + p.pad_lo[2];
+        float acc = 0.f, cnt = 0.f;
+        for (int wi = 0; wi < p.nwin; ++wi) {
+            const int* st = p.starts + wi * 3;
+            const int lz = pz - st[0], ly = py - st[1], lx = px - st[2];
+            if ((unsigned)lz < (unsigned)p.roi[0] && (unsigned)ly < (unsigned)p.roi[1] && (unsigned)lx < (unsigned)p.roi[2]) {
+                acc += p.win_out[((size_t)(b * p.nwin + wi)) * rpix + ((size_t)lz * p.roi[1] + ly) * p.roi[2] + lx];
+                cnt += 1.f;
+            }
+        }
+        p.out[(size_t)b * ipix + i] = acc / cnt;
+    }
+}
+
+// dst[pix][coff..coff+c) += src[pix][...]   (channels-last, 16-byte vectors)
+template <class TR>
+__global__ __launch_bounds__(256) void add_kernel(char* dst, int dpitch, int dcoff, const char* src, int spitch,
+                                                  int scoff, int c, long long npix) {
+    constexpr int VEC = TR::VEC, ESZ = TR::ESZ;
+    const int cvn = c / VEC;
+    const long long nvec = npix * cvn;
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long long)gridDim.x * 256) {
+        const long long pix = v / cvn; const int cv = (int)(v - pix * cvn);
+        float a[VEC], b[VEC];
+        load_vec<TR>(dst + ((size_t)pix * dpitch + dcoff + cv * VEC) * ESZ, a);
+        load_vec<TR>(src + ((size_t)pix * spitch + scoff + cv * VEC) * ESZ, b);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) a[e] += b[e];
+        store_vec<TR>(dst + ((size_t)pix * dpitch + dcoff + cv * VEC) * ESZ, a);
+    }
+}
+
+// labels == 2 -> 1, in place (reference/train.py:112-113)
+__global__ __launch_bounds__(256) void fold_labels_kernel(void* t, int tdtype, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        switch (tdtype) {
+            case 1: { unsigned char* q = (unsigned char*)t; if (q[i] == 2) q[i] = 1; } break;
+            case 2: { long long* q = (long long*)t; if (q[i] == 2) q[i] = 1; } break;
+            case 3: { int* q = (int*)t; if (q[i] == 2) q[i] = 1; } break;
+            default: { float* q = (float*)t; if (q[i] == 2.0f) q[i] = 1.0f; } break;
+        }
+    }
+}
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { mi_set_error(std::string(what) + ": " + hipGetErrorString(e)); return -2; }
+    return 0;
+}
+
+int grid_for(long long n, int per_block, int cap) {
+    long long g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+}  // namespace
+
+// sums ([nb][4] floats) is zeroed here, then filled; loss[0] is written; loss_accum (optional) is accumulated.
+int launch_loss_fwd(const LossParams& p, hipStream_t st) {
+    MI_HIP(hipMemsetAsync(p.sums, 0, (size_t)p.nb * 4 * sizeof(float), st));
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(grid_for(p.npix, 2048, 128), p.nb), dim3(256), 0, st, p);
+    if (int r = check_launch("loss_reduce")) return r;
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, p);
+    return check_launch("loss_finalize");
+}
+
+int launch_loss_bwd(const LossParams& p, hipStream_t st) {
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3(grid_for(p.npix, 1024, 256), p.nb), dim3(256), 0, st, p);
+    return check_launch("loss_bwd");
+}
+
+int launch_dice_counts(const CountParams& p, hipStream_t st) {
+    MI_HIP(hipMemsetAsync(p.counts, 0, (size_t)p.nb * 4 * sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(dice_counts_kernel, dim3(grid_for(p.npix, 2048, 128), p.nb), dim3(256), 0, st, p);
+    return check_launch("dice_counts");
+}
+
+int launch_adamw(const AdamParams& p, hipStream_t st) {
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(p.n / 4, 256, 2048)), dim3(256), 0, st, p);
+    return check_launch("adamw");
+}
+
+int launch_sw_gather(const SwParams& p, int nwin_launch, hipStream_t st) {
+    const int rpix = p.roi[0] * p.roi[1] * p.roi[2];
+    hipLaunchKernelGGL(sw_gather_kernel, dim3(grid_for(rpix, 1024, 256), nwin_launch), dim3(256), 0, st, p);
+    return check_launch("sw_gather");
+}
+
+int launch_sw_blend(const SwParams& p, hipStream_t st) {
+    const int ipix = p.img[0] * p.img[1] * p.img[2];
+    hipLaunchKernelGGL(sw_blend_kernel, dim3(grid_for(ipix, 1024, 256), p.nb), dim3(256), 0, st, p);
+    return check_launch("sw_blend");
+}
+
+int launch_add(int dtype, char* dst, int dpitch, int dcoff, const char* src, int spitch, int scoff, int c,
+               long long npix, hipStream_t st) {
+    const int vec = dtype ? 8 : 4;
+    MI_CHECK(c % vec == 0, "channels must be a multiple of the 16-byte vector");
+    const int g = grid_for(npix * (c / vec), 1024, 2048);
+    if (dtype) hipLaunchKernelGGL(add_kernel<BF16>, dim3(g), dim3(256), 0, st, dst, dpitch, dcoff, src, spitch, scoff, c, npix);
+    else hipLaunchKernelGGL(add_kernel<F32>, dim3(g), dim3(256), 0, st, dst, dpitch, dcoff, src, spitch, scoff, c, npix);
+    return check_launch("add");
+}
+
+int launch_fold_labels(void* t, int tdtype, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(fold_labels_kernel, dim3(grid_for(n, 1024, 1024)), dim3(256), 0, st, t, tdtype, n);
+    return check_launch("fold_labels");
+}

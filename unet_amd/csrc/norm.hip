@@ -1,0 +1,318 @@
+// Instance-norm (no affine, biased variance) + dropout + PReLU, forward and backward, on
+// channels-last tensors.  Bandwidth-bound: one 16-byte vector per lane per access, the
+// per-(image, channel) statistics come from the producing convolution's epilogue
+// (forward) or from a reduction pass (backward).
+//
+// forward :  xh = (x - mean) * rstd ; d = keep ? xh * scale : 0 ; y = d > 0 ? d : alpha*d ; out = y (+ res)
+// backward:  gd = dy * (d > 0 ? 1 : alpha) ; gh = keep ? gd * scale : 0
+//            dx = rstd * (gh - mean_p(gh) - xh * mean_p(gh * xh)) ;  dalpha = sum dy * min(d, 0)
+#include "common.h"
+#include "kparams.h"
+
+namespace {
+
+// mean / rstd of every channel of image `img` into LDS (2 floats per channel)
+__device__ __forceinline__ void load_moments(const float* stats, int img, int c, int npix, float eps, float* sm) {
+    for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < MI_NSLOT; ++sl) {
+            const float* q = stats + (((size_t)img * MI_NSLOT + sl) * c + ch) * 2;
+            s1 += q[0]; s2 += q[1];
+        }
+        const float inv = 1.0f / (float)npix;
+        const float mean = s1 * inv;
+        float var = s2 * inv - mean * mean;
+        var = var > 0.f ? var : 0.f;
+        sm[ch * 2] = mean;
+        sm[ch * 2 + 1] = rsqrtf(var + eps);
+    }
+}
+
+constexpr int NORM_ITEMS = 8;  // vectors per thread per block
+
+template <class TR>
+__global__ __launch_bounds__(256) void norm_fwd_kernel(const NormParams p) {
+    constexpr int VEC = TR::VEC, ESZ = TR::ESZ;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int img = blockIdx.y;
+    load_moments(p.stats, img, p.c, p.npix, p.eps, sm);
+    __syncthreads();
+    const float alpha = *p.alpha;
+    const int cv_n = p.c / VEC;
+    const long long nvec = (long long)p.npix * cv_n;
+    const long long v0 = (long long)blockIdx.x * 256 * NORM_ITEMS;
+#pragma unroll
+    for (int it = 0; it < NORM_ITEMS; ++it) {
+        const long long v = v0 + it * 256 + threadIdx.x;
+        if (v >= nvec) break;
+        const int pix = (int)(v / cv_n), cv = (int)(v - (long long)pix * cv_n);
+        const size_t gp = (size_t)img * p.npix + pix;
+        const int ch0 = cv * VEC;
+        float x[VEC], r[VEC], o[VEC];
+        load_vec<TR>(p.x + (gp * p.x_pitch + p.x_coff + ch0) * ESZ, x);
+        if (p.res) load_vec<TR>(p.res + (gp * p.res_pitch + p.res_coff + ch0) * ESZ, r);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            float d = (x[e] - sm[(ch0 + e) * 2]) * sm[(ch0 + e) * 2 + 1];
+            if (p.drop_thresh) {
+                const bool keep = dropout_keep(p.seed, p.layer, (unsigned long long)gp * p.c + ch0 + e, p.drop_thresh);
+                d = keep ? d * p.drop_scale : 0.f;
+            }
+            float y = d > 0.f ? d : alpha * d;
+            if (p.res) y += r[e];
+            o[e] = y;
+        }
+        store_vec<TR>(p.out + (gp * p.out_pitch + p.out_coff + ch0) * ESZ, o);
+    }
+}
+
+// backward pass 1: per-(image, channel) sums of gh and gh*xh, and the slope gradient
+template <class TR>
+__global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const NormParams p) {
+    constexpr int VEC = TR::VEC, ESZ = TR::ESZ;
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // [c][2] moments, then [c][2] accumulators
+    const int img = blockIdx.y;
+    float* acc = sm + 2 * p.c;
+    load_moments(p.stats, img, p.c, p.npix, p.eps, sm);
+    for (int i = threadIdx.x; i < 2 * p.c; i += 256) acc[i] = 0.f;
+    __syncthreads();
+    const float alpha = *p.alpha;
+    const int cv_n = p.c / VEC;
+    // a thread keeps one channel vector and walks pixels
+    const int rows = 256 / cv_n > 0 ? 256 / cv_n : 1;   // pixel rows handled per sweep
+    const int cv = threadIdx.x % cv_n, prow = threadIdx.x / cv_n;
+    const int ch0 = cv * VEC;
+    const int pix_per_block = (p.npix + gridDim.x - 1) / gridDim.x;
+    const int pbeg = blockIdx.x * pix_per_block;
+    const int pend = min(p.npix, pbeg + pix_per_block);
+    float s1[VEC], s2[VEC], da = 0.f;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    if (prow < rows && cv_n <= 256) {
+        for (int pix = pbeg + prow; pix < pend; pix += rows) {
+            const size_t gp = (size_t)img * p.npix + pix;
+            float x[VEC], dy[VEC];
+            load_vec<TR>(p.x + (gp * p.x_pitch + p.x_coff + ch0) * ESZ, x);
+            load_vec<TR>(p.dy + (gp * p.dy_pitch + p.dy_coff + ch0) * ESZ, dy);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float xh = (x[e] - sm[(ch0 + e) * 2]) * sm[(ch0 + e) * 2 + 1];
+                float d = xh, sc = 1.f;
+                if (p.drop_thresh) {
+                    const bool keep =
+                        dropout_keep(p.seed, p.layer, (unsigned long long)gp * p.c + ch0 + e, p.drop_thresh);
+                    sc = keep ? p.drop_scale : 0.f;
+                    d = xh * sc;
+                }
+                const float gd = dy[e] * (d > 0.f ? 1.f : alpha);
+                da += dy[e] * fminf(d, 0.f);
+                const float gh = gd * sc;
+                s1[e] += gh; s2[e] += gh * xh;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            atomicAdd(&acc[(ch0 + e) * 2], s1[e]);
+            atomicAdd(&acc[(ch0 + e) * 2 + 1], s2[e]);
+        }
+    }
+    da = wave_sum(da);
+    __syncthreads();
+    const int slot = blockIdx.x % MI_NSLOT;
+    for (int i = threadIdx.x; i < 2 * p.c; i += 256)
+        atomicAdd(&p.bstats[(((size_t)img * MI_NSLOT + slot) * p.c) * 2 + i], acc[i]);
+    if ((threadIdx.x & 63) == 0 && p.dalpha) atomicAdd(p.dalpha, da);
+}
+
+// backward pass 2: dx
+template <class TR>
+__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const NormParams p) {
+    constexpr int VEC = TR::VEC, ESZ = TR::ESZ;
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // [c][2] moments, [c][2] backward means
+    const int img = blockIdx.y;
+    float* bm = sm + 2 * p.c;
+    load_moments(p.stats, img, p.c, p.npix, p.eps, sm);
+    for (int i = threadIdx.x; i < 2 * p.c; i += 256) {
+        float a = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < MI_NSLOT; ++sl) a += p.bstats[(((size_t)img * MI_NSLOT + sl) * p.c) * 2 + i];
+        bm[i] = a / (float)p.npix;
+    }
+    __syncthreads();
+    const float alpha = *p.alpha;
+    const int cv_n = p.c / VEC;
+    const long long nvec = (long long)p.npix * cv_n;
+    const long long v0 = (long long)blockIdx.x * 256 * NORM_ITEMS;
+#pragma unroll
+    for (int it = 0; it < NORM_ITEMS; ++it) {
+        const long long v = v0 + it * 256 + threadIdx.x;
+        if (v >= nvec) break;
+        const int pix = (int)(v / cv_n), cv = (int)(v - (long long)pix * cv_n);
+        const size_t gp = (size_t)img * p.npix + pix;
+        const int ch0 = cv * VEC;
+        float x[VEC], dy[VEC], o[VEC];
+        load_vec<TR>(p.x + (gp * p.x_pitch + p.x_coff + ch0) * ESZ, x);
+        load_vec<TR>(p.dy + (gp * p.dy_pitch + p.dy_coff + ch0) * ESZ, dy);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float rstd = sm[(ch0 + e) * 2 + 1];
+            const float xh = (x[e] - sm[(ch0 + e) * 2]) * rstd;
+            float d = xh, sc = 1.f;
+            if (p.drop_thresh) {
+                const bool keep = dropout_keep(p.seed, p.layer, (unsigned long long)gp * p.c + ch0 + e, p.drop_thresh);
+                sc = keep ? p.drop_scale : 0.f;
+                d = xh * sc;
+            }
+            const float gh = dy[e] * (d > 0.f ? 1.f : alpha) * sc;
+            o[e] = rstd * (gh - bm[(ch0 + e) * 2] - xh * bm[(ch0 + e) * 2 + 1]);
+        }
+        store_vec<TR>(p.out + (gp * p.out_pitch + p.out_coff + ch0) * ESZ, o);
+    }
+}
+
+// ---- one-channel fp32 planar variants (top of the decoder) ------------------------
+// tensors are [nb][npix] fp32; four consecutive pixels per lane.
+__device__ __forceinline__ void c1_moments(const float* stats, int img, int npix, float eps, float& mean, float& rstd) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < MI_NSLOT; ++sl) {
+        s1 += stats[((size_t)img * MI_NSLOT + sl) * 2];
+        s2 += stats[((size_t)img * MI_NSLOT + sl) * 2 + 1];
+    }
+    mean = s1 / (float)npix;
+    float var = s2 / (float)npix - mean * mean;
+    var = var > 0.f ? var : 0.f;
+    rstd = rsqrtf(var + eps);
+}
+
+__global__ __launch_bounds__(256) void norm1_fwd_kernel(const NormParams p) {
+    const int img = blockIdx.y;
+    float mean, rstd;
+    c1_moments(p.stats, img, p.npix, p.eps, mean, rstd);
+    const float alpha = *p.alpha;
+    const float* x = reinterpret_cast<const float*>(p.x) + (size_t)img * p.npix;
+    float* out = reinterpret_cast<float*>(p.out) + (size_t)img * p.npix;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < p.npix; i += gridDim.x * 256) {
+        float d = (x[i] - mean) * rstd;
+        if (p.drop_thresh) {
+            const bool keep = dropout_keep(p.seed, p.layer, (unsigned long long)img * p.npix + i, p.drop_thresh);
+            d = keep ? d * p.drop_scale : 0.f;
+        }
+        out[i] = d > 0.f ? d : alpha * d;
+    }
+}
+
+__global__ __launch_bounds__(256) void norm1_bwd_reduce_kernel(const NormParams p) {
+    __shared__ float red[3][4];
+    const int img = blockIdx.y;
+    float mean, rstd;
+    c1_moments(p.stats, img, p.npix, p.eps, mean, rstd);
+    const float alpha = *p.alpha;
+    const float* x = reinterpret_cast<const float*>(p.x) + (size_t)img * p.npix;
+    const float* dy = reinterpret_cast<const float*>(p.dy) + (size_t)img * p.npix;
+    float s1 = 0.f, s2 = 0.f, da = 0.f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < p.npix; i += gridDim.x * 256) {
+        const float xh = (x[i] - mean) * rstd;
+        float d = xh, sc = 1.f;
+        if (p.drop_thresh) {
+            const bool keep = dropout_keep(p.seed, p.layer, (unsigned long long)img * p.npix + i, p.drop_thresh);
+            sc = keep ? p.drop_scale : 0.f;
+            d = xh * sc;
+        }
+        const float g = dy[i];
+        const float gh = g * (d > 0.f ? 1.f : alpha) * sc;
+        da += g * fminf(d, 0.f);
+        s1 += gh; s2 += gh * xh;
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2); da = wave_sum(da);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][w] = s1; red[1][w] = s2; red[2][w] = da; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int slot = blockIdx.x % MI_NSLOT;
+        atomicAdd(&p.bstats[((size_t)img * MI_NSLOT + slot) * 2], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        atomicAdd(&p.bstats[((size_t)img * MI_NSLOT + slot) * 2 + 1], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+        if (p.dalpha) atomicAdd(p.dalpha, red[2][0] + red[2][1] + red[2][2] + red[2][3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void norm1_bwd_apply_kernel(const NormParams p) {
+    const int img = blockIdx.y;
+    float mean, rstd;
+    c1_moments(p.stats, img, p.npix, p.eps, mean, rstd);
+    float b1 = 0.f, b2 = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < MI_NSLOT; ++sl) {
+        b1 += p.bstats[((size_t)img * MI_NSLOT + sl) * 2];
+        b2 += p.bstats[((size_t)img * MI_NSLOT + sl) * 2 + 1];
+    }
+    b1 /= (float)p.npix; b2 /= (float)p.npix;
+    const float alpha = *p.alpha;
+    const float* x = reinterpret_cast<const float*>(p.x) + (size_t)img * p.npix;
+    const float* dy = reinterpret_cast<const float*>(p.dy) + (size_t)img * p.npix;
+    float* out = reinterpret_cast<float*>(p.out) + (size_t)img * p.npix;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < p.npix; i += gridDim.x * 256) {
+        const float xh = (x[i] - mean) * rstd;
+        float d = xh, sc = 1.f;
+        if (p.drop_thresh) {
+            const bool keep = dropout_keep(p.seed, p.layer, (unsigned long long)img * p.npix + i, p.drop_thresh);
+            sc = keep ? p.drop_scale : 0.f;
+            d = xh * sc;
+        }
+        const float gh = dy[i] * (d > 0.f ? 1.f : alpha) * sc;
+        out[i] = rstd * (gh - b1 - xh * b2);
+    }
+}
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { mi_set_error(std::string(what) + ": " + hipGetErrorString(e)); return -2; }
+    return 0;
+}
+
+}  // namespace
+
+// dtype: 0 fp32, 1 bf16.  c == 1 selects the planar fp32 kernels (pitch must be 1, dtype 0).
+int launch_norm_fwd(int dtype, const NormParams& p, hipStream_t st) {
+    if (p.c == 1) {
+        MI_CHECK(dtype == 0 && p.x_pitch == 1 && p.out_pitch == 1 && !p.res, "one-channel tensors are planar fp32");
+        int gx = (p.npix + 1023) / 1024; if (gx > 256) gx = 256;
+        hipLaunchKernelGGL(norm1_fwd_kernel, dim3(gx, p.nb), dim3(256), 0, st, p);
+        return check_launch("norm1_fwd");
+    }
+    const int vec = dtype ? 8 : 4;
+    MI_CHECK(p.c % vec == 0, "channels must be a multiple of the 16-byte vector");
+    const long long nvec = (long long)p.npix * (p.c / vec);
+    const int gx = (int)((nvec + 256 * NORM_ITEMS - 1) / (256 * NORM_ITEMS));
+    const size_t lds = (size_t)p.c * 2 * sizeof(float);
+    if (dtype) hipLaunchKernelGGL(norm_fwd_kernel<BF16>, dim3(gx, p.nb), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL(norm_fwd_kernel<F32>, dim3(gx, p.nb), dim3(256), lds, st, p);
+    return check_launch("norm_fwd");
+}
+
+// bstats ([nb][NSLOT][c][2] floats) must be zero on entry; dalpha is accumulated into.
+int launch_norm_bwd(int dtype, const NormParams& p, hipStream_t st) {
+    if (p.c == 1) {
+        MI_CHECK(dtype == 0 && p.x_pitch == 1 && p.out_pitch == 1 && p.dy_pitch == 1, "one-channel tensors are planar fp32");
+        int gx = (p.npix + 2047) / 2048; if (gx > 128) gx = 128;
+        hipLaunchKernelGGL(norm1_bwd_reduce_kernel, dim3(gx, p.nb), dim3(256), 0, st, p);
+        if (int r = check_launch("norm1_bwd_reduce")) return r;
+        int ga = (p.npix + 1023) / 1024; if (ga > 256) ga = 256;
+        hipLaunchKernelGGL(norm1_bwd_apply_kernel, dim3(ga, p.nb), dim3(256), 0, st, p);
+        return check_launch("norm1_bwd_apply");
+    }
+    const int vec = dtype ? 8 : 4;
+    MI_CHECK(p.c % vec == 0, "channels must be a multiple of the 16-byte vector");
+    MI_CHECK(p.c / vec <= 256, "too many channels for the reduction kernel");
+    const size_t lds = (size_t)p.c * 4 * sizeof(float);
+    int gr = (p.npix + 2047) / 2048; if (gr < 1) gr = 1; if (gr > 256) gr = 256;
+    if (dtype) hipLaunchKernelGGL(norm_bwd_reduce_kernel<BF16>, dim3(gr, p.nb), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL(norm_bwd_reduce_kernel<F32>, dim3(gr, p.nb), dim3(256), lds, st, p);
+    if (int r = check_launch("norm_bwd_reduce")) return r;
+    const long long nvec = (long long)p.npix * (p.c / vec);
+    const int gx = (int)((nvec + 256 * NORM_ITEMS - 1) / (256 * NORM_ITEMS));
+    if (dtype) hipLaunchKernelGGL(norm_bwd_apply_kernel<BF16>, dim3(gx, p.nb), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL(norm_bwd_apply_kernel<F32>, dim3(gx, p.nb), dim3(256), lds, st, p);
+    return check_launch("norm_bwd_apply");
+}

@@ -1,0 +1,127 @@
+"""Operator-level Python bindings (channels-last tensors) over the C ABI: convolution forward / data
+gradient / weight gradient and instance-norm + PReLU.  Used by the operator parity tests and by
+callers that want to assemble other networks from the same kernels.
+
+Tensors are ``[N, (D,) H, W, C]`` contiguous, dtype ``torch.bfloat16`` or ``torch.float32``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+_DT = {torch.float32: 0, torch.bfloat16: 1}
+
+
+def _desc(x_shape, cin, cout, ksize, stride, transposed, dtype):
+    d = _lib.MiConvDesc()
+    nd = len(x_shape) - 2
+    d.ndim, d.transposed, d.ksize, d.stride = nd, 1 if transposed else 0, ksize, stride
+    d.cin, d.cout, d.nb = cin, cout, x_shape[0]
+    sp = [1] * (3 - nd) + [int(v) for v in x_shape[1:-1]]
+    for i in range(3):
+        d.in_dims[i] = sp[i]
+    d.dtype = _DT[dtype]
+    return d
+
+
+def _ten(t: Optional[torch.Tensor], coff: int = 0):
+    m = _lib.MiTensor()
+    if t is not None:
+        m.ptr, m.pitch, m.coff = t.data_ptr(), t.shape[-1], coff
+    return m
+
+
+def _out_spatial(sp, ksize, stride, transposed):
+    if transposed:
+        return [2 * s for s in sp]
+    pad = (ksize - 1) // 2
+    return [(s + 2 * pad - ksize) // stride + 1 for s in sp]
+
+
+def pack_weights(w: torch.Tensor, x_shape, ksize, stride, transposed, dtype, dgrad=False) -> torch.Tensor:
+    lib = _lib.load()
+    cin, cout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
+    d = _desc(x_shape, cin, cout, ksize, stride, transposed, dtype)
+    nbytes = lib.mi_conv_packed_bytes(C.byref(d))
+    out = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    wf = w.contiguous().float()
+    _lib.check(lib.mi_conv_pack(C.byref(d), 1 if dgrad else 0, wf.data_ptr(), out.data_ptr(),
+                                _lib.current_stream(w.device)), "mi_conv_pack")
+    return out
+
+
+def conv_forward(x, w, bias=None, ksize=3, stride=1, transposed=False, addend=None, want_stats=False):
+    """x: channels-last; w: torch layout fp32.  Returns y (channels-last) [, stats [N,8,Cout,2]]."""
+    lib = _lib.load()
+    cin, cout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
+    d = _desc(x.shape, cin, cout, ksize, stride, transposed, x.dtype)
+    packed = pack_weights(w, x.shape, ksize, stride, transposed, x.dtype, False)
+    osp = _out_spatial(list(x.shape[1:-1]), ksize, stride, transposed)
+    y = torch.empty([x.shape[0]] + osp + [cout], dtype=x.dtype, device=x.device)
+    stats = torch.zeros(x.shape[0], 8, cout, 2, dtype=torch.float32, device=x.device) if want_stats else None
+    b = bias.contiguous().float() if bias is not None else None
+    tx, ty, ta = _ten(x), _ten(y), _ten(addend)
+    _lib.check(lib.mi_conv_forward(C.byref(d), C.byref(tx), packed.data_ptr(), _lib.ptr(b), C.byref(ty),
+                                   C.byref(ta) if addend is not None else None, _lib.ptr(stats),
+                                   _lib.current_stream(x.device)), "mi_conv_forward")
+    return (y, stats) if want_stats else y
+
+
+def conv_dgrad(dy, w, x_shape, ksize=3, stride=1, transposed=False, addend=None):
+    lib = _lib.load()
+    cin, cout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
+    d = _desc(x_shape, cin, cout, ksize, stride, transposed, dy.dtype)
+    packed = pack_weights(w, x_shape, ksize, stride, transposed, dy.dtype, True)
+    dx = torch.empty(list(x_shape[:-1]) + [cin], dtype=dy.dtype, device=dy.device)
+    tdy, tdx, ta = _ten(dy), _ten(dx), _ten(addend)
+    _lib.check(lib.mi_conv_dgrad(C.byref(d), C.byref(tdy), packed.data_ptr(), C.byref(tdx),
+                                 C.byref(ta) if addend is not None else None, _lib.current_stream(dy.device)),
+               "mi_conv_dgrad")
+    return dx
+
+
+def conv_wgrad(x, dy, w_shape, ksize=3, stride=1, transposed=False):
+    """Returns (dw in the torch layout, db [cout] or None for transposed convolutions)."""
+    lib = _lib.load()
+    cin, cout = (w_shape[0], w_shape[1]) if transposed else (w_shape[1], w_shape[0])
+    d = _desc(x.shape, cin, cout, ksize, stride, transposed, x.dtype)
+    ws = torch.empty(lib.mi_conv_wgrad_workspace_bytes(C.byref(d)), dtype=torch.uint8, device=x.device)
+    dw = torch.empty(w_shape, dtype=torch.float32, device=x.device)
+    db = None if transposed else torch.empty(cout, dtype=torch.float32, device=x.device)
+    tx, tdy = _ten(x), _ten(dy)
+    _lib.check(lib.mi_conv_wgrad(C.byref(d), C.byref(tx), C.byref(tdy), dw.data_ptr(), _lib.ptr(db), ws.data_ptr(),
+                                 _lib.current_stream(x.device)), "mi_conv_wgrad")
+    return dw, db
+
+
+def instnorm_prelu_fwd(raw, stats, alpha, res=None, dropout=0.0, seed=0, layer=0):
+    lib = _lib.load()
+    nb, c = raw.shape[0], raw.shape[-1]
+    npix = raw[0].numel() // c
+    out = torch.empty_like(raw)
+    traw, tres, tout = _ten(raw), _ten(res), _ten(out)
+    _lib.check(lib.mi_instnorm_prelu_fwd(_DT[raw.dtype], nb, npix, c, C.byref(traw), stats.data_ptr(), alpha.data_ptr(),
+                                         C.byref(tres) if res is not None else None, C.byref(tout), float(dropout),
+                                         C.c_uint64(seed), layer, _lib.current_stream(raw.device)),
+               "mi_instnorm_prelu_fwd")
+    return out
+
+
+def instnorm_prelu_bwd(dy, raw, stats, alpha, dropout=0.0, seed=0, layer=0):
+    """Returns (dx, dalpha [1])."""
+    lib = _lib.load()
+    nb, c = raw.shape[0], raw.shape[-1]
+    npix = raw[0].numel() // c
+    dx = torch.empty_like(raw)
+    bstats = torch.empty(nb * 8 * c * 2, dtype=torch.float32, device=raw.device)
+    dalpha = torch.zeros(1, dtype=torch.float32, device=raw.device)
+    tdy, traw, tdx = _ten(dy), _ten(raw), _ten(dx)
+    _lib.check(lib.mi_instnorm_prelu_bwd(_DT[raw.dtype], nb, npix, c, C.byref(tdy), C.byref(traw), stats.data_ptr(),
+                                         alpha.data_ptr(), bstats.data_ptr(), dalpha.data_ptr(), C.byref(tdx),
+                                         float(dropout), C.c_uint64(seed), layer, _lib.current_stream(raw.device)),
+               "mi_instnorm_prelu_bwd")
+    return dx, dalpha

@@ -1,0 +1,104 @@
+"""Data-parallel pieces (new capability: the reference is single-device, reference/train.py:75).
+
+One process per GPU, ``torch.distributed`` (backend "nccl" = RCCL over xGMI on ROCm; "gloo" on CPU for
+tests).  Training: the batch is sharded, every rank holds a replica, gradients live in ONE flat
+fp32 buffer that the engine fills in three buckets in backward-completion order (decoder, bottom,
+encoder); each bucket is all-reduced on a side stream as soon as its part of the backward has been
+enqueued, overlapping the rest of the backward.  Instance norm needs no cross-rank statistics.
+Inference: independent slices are sharded; the only exchange is the final sum of Dice partials.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """Initialises the default process group from RANK / WORLD_SIZE / MASTER_* (torchrun's environment).
+    Returns (rank, world_size, local_rank); a plain single-process run gives (0, 1, 0)."""
+    import os
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+class BucketedAllReduce:
+    """All-reduce (sum) of contiguous buckets of one flat gradient buffer, asynchronously.
+
+    ``launch(i)`` must be called after the work that produces bucket ``i`` has been enqueued on the
+    current stream; ``wait()`` makes the current stream (GPU) or the host (CPU tensors) wait for all
+    launched buckets.  Averaging is left to the consumer (the fused AdamW takes ``grad_scale``).
+    """
+
+    def __init__(self, flat: torch.Tensor, buckets: Sequence[Tuple[int, int]], group=None):
+        self.flat = flat
+        self.buckets = [(int(o), int(c)) for o, c in buckets]
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._works: List = []
+        self._comm_stream = torch.cuda.Stream(flat.device) if flat.is_cuda else None
+        self._events: List = []
+
+    def launch(self, i: int) -> None:
+        if self.world == 1:
+            return
+        o, c = self.buckets[i]
+        if c == 0:
+            return
+        view = self.flat[o:o + c]
+        if self._comm_stream is not None:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(self.flat.device))
+            with torch.cuda.stream(self._comm_stream):
+                self._comm_stream.wait_event(ready)
+                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+                done = torch.cuda.Event()
+                done.record(self._comm_stream)
+            self._events.append(done)
+        else:
+            self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self) -> None:
+        for w in self._works:
+            w.wait()
+        self._works = []
+        if self._events:
+            cur = torch.cuda.current_stream(self.flat.device)
+            for e in self._events:
+                cur.wait_event(e)
+            self._events = []
+
+
+def shard_batch(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """[lo, hi) of a global batch / slice list owned by ``rank`` (contiguous, sizes differ by at most 1)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def all_reduce_dice_partials(partials: torch.Tensor, group=None) -> torch.Tensor:
+    """Sums per-volume Dice partials ([..., k] tensors of slice-dice sums and counts, or tp/fp/fn counts)
+    over the ranks: the one collective of sharded inference."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(partials, op=dist.ReduceOp.SUM, group=group)
+    return partials
+
+
+def broadcast_parameters(flat: torch.Tensor, src: int = 0, group=None) -> None:
+    """Makes every replica start from rank ``src``'s parameters."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(flat, src=src, group=group)

@@ -1,0 +1,109 @@
+"""Fused training step: the body of the reference's inner loop (reference/train.py:111-119) as one
+sequence of HIP launches on one stream with no host synchronisation and no Python per layer:
+
+    labels==2 -> 1 (folded into the loss read) -> forward -> Dice(+CE) loss -> backward
+    -> bucketed gradient all-reduce (overlapped, multi-GPU only) -> AdamW
+
+``loss.item()`` per step (train.py:119) is replaced by a device-side running sum read once per epoch.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from .losses import DiceCELoss
+from .nets import UNet
+from .optim import AdamW
+from .parallel import BucketedAllReduce
+
+
+class Trainer:
+    def __init__(self, model: UNet, loss: DiceCELoss, optimizer: AdamW, *, group=None, overlap: bool = True):
+        self.model, self.loss, self.opt = model, loss, optimizer
+        optimizer.bind(model)
+        self.group = group
+        self.overlap = overlap
+        self._bufs = {}
+        self._reducer = None
+        self._grad = None
+        import torch.distributed as dist
+
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def _buffers(self, x):
+        key = (tuple(x.shape), x.device)
+        b = self._bufs.get(key)
+        if b is None:
+            dev = x.device
+            plan = self.model._plan_for(x, True)
+            b = dict(plan=plan, logits=torch.empty_like(x), dlogits=torch.empty_like(x),
+                     sums=torch.empty(x.shape[0] * 4, dtype=torch.float32, device=dev),
+                     loss=torch.zeros(1, dtype=torch.float32, device=dev),
+                     ws=torch.empty(plan.workspace_bytes, dtype=torch.uint8, device=dev))
+            self._bufs[key] = b
+        return b
+
+    def loss_sum(self) -> float:
+        """Sum of the step losses since the last call (synchronises once)."""
+        if getattr(self, "_loss_accum", None) is None:
+            return 0.0
+        v = float(self._loss_accum.item())
+        self._loss_accum.zero_()
+        return v
+
+    def last_logits(self, x) -> torch.Tensor:
+        return self._buffers(x)["logits"]
+
+    @torch.no_grad()
+    def step(self, x: torch.Tensor, labels: torch.Tensor) -> None:
+        model = self.model
+        model._check_input(x)
+        if not model.training:
+            raise RuntimeError("Trainer.step needs model.train()")
+        lib = _lib.load()
+        x = x.contiguous()
+        if x.dtype != torch.float32:
+            x = x.float()
+        labels = labels.contiguous()
+        tcode = _lib.label_dtype_code(labels)
+        if tcode < 0:
+            labels = labels.float()
+            tcode = 0
+        if labels.shape != x.shape:
+            raise AssertionError(f"ground truth has different shape ({labels.shape}) from input ({x.shape})")
+        dev = x.device
+        flat = model._ensure_flat(dev)
+        b = self._buffers(x)
+        plan = b["plan"]
+        if self._grad is None or self._grad.device != dev:
+            self._grad = torch.zeros_like(flat)
+            self._loss_accum = torch.zeros(1, dtype=torch.float32, device=dev)
+            self._reducer = BucketedAllReduce(self._grad, model.gradient_buckets(), self.group) if self.world > 1 else None
+        st = _lib.current_stream(dev)
+        seed = model._next_seed()
+        nb, npix = x.shape[0], x[0].numel()
+        L = self.loss
+        plan.forward(flat, x, b["logits"], b["ws"], True, seed)
+        _lib.check(lib.mi_dice_ce_loss_fwd(b["logits"].data_ptr(), labels.data_ptr(), tcode, 1 if L.fold_label_two else 0,
+                                           nb, npix, L.smooth_nr, L.smooth_dr, L.lambda_dice, L.lambda_ce,
+                                           b["sums"].data_ptr(), b["loss"].data_ptr(), self._loss_accum.data_ptr(), st),
+                   "mi_dice_ce_loss_fwd")
+        _lib.check(lib.mi_dice_ce_loss_bwd(b["logits"].data_ptr(), labels.data_ptr(), tcode, 1 if L.fold_label_two else 0,
+                                           nb, npix, L.smooth_nr, L.smooth_dr, L.lambda_dice, L.lambda_ce,
+                                           b["sums"].data_ptr(), 0, 1.0, b["dlogits"].data_ptr(), st),
+                   "mi_dice_ce_loss_bwd")
+        if self._reducer is not None and self.overlap:
+            for bucket in range(3):
+                plan.backward(flat, b["dlogits"], self._grad, b["ws"], True, seed, bucket)
+                self._reducer.launch(bucket)
+            self._reducer.wait()
+        else:
+            plan.backward(flat, b["dlogits"], self._grad, b["ws"], True, seed, -1)
+            if self._reducer is not None:
+                for bucket in range(3):
+                    self._reducer.launch(bucket)
+                self._reducer.wait()
+        self.opt.step(flat_grad=self._grad, grad_scale=1.0 / self.world)
