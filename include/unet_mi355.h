@@ -73,10 +73,11 @@ int mi_unet_num_steps(const mi_unet* u, int backward);         /* kernel launche
 int mi_unet_forward(mi_unet* u, const float* params, const float* x, float* logits, void* workspace,
                     int training, uint64_t seed, void* stream);
 /* grads (flat fp32, same layout as params) of the forward that last used `workspace`.
+ * `x` is the forward's input (the first layer's weight gradient reads it);
  * `training` and `seed` must repeat the forward's values (the dropout mask is recomputed, not stored).
  * bucket < 0: whole backward; otherwise buckets must be run in order 0,1,2. */
-int mi_unet_backward(mi_unet* u, const float* params, const float* dlogits, float* grads, void* workspace,
-                     int training, uint64_t seed, int bucket, void* stream);
+int mi_unet_backward(mi_unet* u, const float* params, const float* x, const float* dlogits, float* grads,
+                     void* workspace, int training, uint64_t seed, int bucket, void* stream);
 
 /* Per-launch timing: when enabled every kernel launch of the engine is bracketed by HIP events on
  * its stream.  mi_unet_prof_collect() synchronises those events and adds the elapsed times to the
@@ -93,6 +94,9 @@ typedef struct mi_step_info {
     int64_t launches;
 } mi_step_info;
 int mi_unet_step_info(const mi_unet* u, int backward, int i, mi_step_info* info);
+/* debug aid: workspace offset of the tensor step i writes (-1: outside the workspace) */
+int64_t mi_unet_step_output_offset(const mi_unet* u, int backward, int i);
+int64_t mi_unet_step_aux_offset(const mi_unet* u, int backward, int i);   /* statistics block of a norm step */
 
 /* ------------------------------------------------------------------------------------------
  * Loss / metric.  Replaces DiceCELoss(to_onehot_y=False, sigmoid=True)(outputs, labels) and its
@@ -102,11 +106,11 @@ int mi_unet_step_info(const mi_unet* u, int backward, int i, mi_step_info* info)
  * ------------------------------------------------------------------------------------------ */
 int mi_dice_ce_loss_fwd(const float* logits, const void* target, int target_dtype, int fold2, int nb,
                         int64_t npix, float smooth_nr, float smooth_dr, float lambda_dice, float lambda_ce,
-                        float* sums /* [nb][4] scratch, kept for backward */, float* loss /* [1] */,
+                        double* sums /* [nb][4] scratch, kept for backward */, float* loss /* [1] */,
                         float* loss_accum /* optional running sum */, void* stream);
 int mi_dice_ce_loss_bwd(const float* logits, const void* target, int target_dtype, int fold2, int nb,
                         int64_t npix, float smooth_nr, float smooth_dr, float lambda_dice, float lambda_ce,
-                        const float* sums, const float* grad_out /* optional device scalar */, float grad_scale,
+                        const double* sums, const float* grad_out /* optional device scalar */, float grad_scale,
                         float* dlogits, void* stream);
 int mi_dice_counts(const float* pred, int pred_is_binary, float thresh, const void* target, int target_dtype,
                    int fold2, int nb, int64_t npix, uint64_t* counts /* [nb][4] tp,fp,fn,tn */, void* stream);
@@ -154,9 +158,10 @@ typedef struct mi_tensor {
 size_t mi_conv_packed_bytes(const mi_conv_desc* d);
 int mi_conv_pack(const mi_conv_desc* d, int dgrad, const float* w, void* packed, void* stream);
 /* F.conv{2,3}d / F.conv_transpose{2,3}d: y = conv(x) (+bias) (+addend); stats (optional) receives
- * per-(image, slot, channel) sum and sum of squares of the bias-free result ([nb][8][cout][2], pre-zeroed) */
+ * per-(image, slot, channel) sum and sum of squares of the bias-free result ([nb][8][cout][2] fp64,
+ * pre-zeroed; fp64 accumulators make the sums independent of workgroup arrival order) */
 int mi_conv_forward(const mi_conv_desc* d, const mi_tensor* x, const void* packed, const float* bias,
-                    const mi_tensor* y, const mi_tensor* addend, float* stats, void* stream);
+                    const mi_tensor* y, const mi_tensor* addend, double* stats, void* stream);
 int mi_conv_dgrad(const mi_conv_desc* d, const mi_tensor* dy, const void* packed_dgrad, const mi_tensor* dx,
                   const mi_tensor* addend, void* stream);
 size_t mi_conv_wgrad_workspace_bytes(const mi_conv_desc* d);
@@ -165,12 +170,12 @@ int mi_conv_wgrad(const mi_conv_desc* d, const mi_tensor* x, const mi_tensor* dy
                   void* workspace, void* stream);
 
 /* InstanceNorm(eps, no affine) -> Dropout(p) -> PReLU(alpha) (+ residual): MONAI ADN "NDA" */
-int mi_instnorm_prelu_fwd(int dtype, int nb, int64_t npix, int c, const mi_tensor* raw, const float* stats,
+int mi_instnorm_prelu_fwd(int dtype, int nb, int64_t npix, int c, const mi_tensor* raw, const double* stats,
                           const float* alpha, const mi_tensor* res, const mi_tensor* out, float dropout,
                           uint64_t seed, uint32_t layer, void* stream);
-/* bstats: [nb][8][c][2] scratch (zeroed inside); dalpha: device scalar, accumulated */
+/* bstats: [nb][8][c][2] fp64 scratch (zeroed inside); dalpha: device scalar, accumulated */
 int mi_instnorm_prelu_bwd(int dtype, int nb, int64_t npix, int c, const mi_tensor* dy, const mi_tensor* raw,
-                          const float* stats, const float* alpha, float* bstats, float* dalpha,
+                          const double* stats, const float* alpha, double* bstats, float* dalpha,
                           const mi_tensor* dx, float dropout, uint64_t seed, uint32_t layer, void* stream);
 
 #ifdef __cplusplus

@@ -73,7 +73,7 @@ def test_conv_forward_dgrad_wgrad(dev, mode, case):
     nob = (y_ref.detach() - b.view(1, -1, *([1] * nd)))
     s1 = nob.flatten(2).sum(-1)
     s2 = (nob * nob).flatten(2).sum(-1)
-    st = stats.cpu().sum(1)
+    st = stats.cpu().sum(1).float()
     assert rel_err(st[..., 0], s1) < 1e-4 and rel_err(st[..., 1], s2) < 1e-4
 
     dyc = to_cl(dy, dt, dev)
@@ -125,7 +125,7 @@ def test_instnorm_prelu_fwd_bwd(dev, mode, nd, sp, c):
     # statistics as the producing convolution would deliver them (sums split over the 8 slots)
     s1 = x.flatten(2).sum(-1)
     s2 = (x * x).flatten(2).sum(-1)
-    stats = torch.zeros(nb, 8, c, 2)
+    stats = torch.zeros(nb, 8, c, 2, dtype=torch.float64)
     stats[:, 0, :, 0], stats[:, 3, :, 1] = s1, s2
     stats = stats.to(dev)
     xc, rc, dyc = to_cl(x, dt, dev), to_cl(res, dt, dev), to_cl(dy, dt, dev)
@@ -145,7 +145,7 @@ def test_dropout_statistics_and_mask_replay(dev):
     x = torch.randn(nb, c, *sp, generator=g)
     s1 = x.flatten(2).sum(-1)
     s2 = (x * x).flatten(2).sum(-1)
-    stats = torch.zeros(nb, 8, c, 2)
+    stats = torch.zeros(nb, 8, c, 2, dtype=torch.float64)
     stats[:, 0, :, 0], stats[:, 0, :, 1] = s1, s2
     stats = stats.to(dev)
     alpha = torch.tensor([0.25], device=dev)

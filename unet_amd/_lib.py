@@ -68,11 +68,13 @@ PROTOTYPES = {
     "mi_unet_flops": (C.c_double, [_P, C.c_int]),
     "mi_unet_num_steps": (C.c_int, [_P, C.c_int]),
     "mi_unet_forward": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_uint64, _P]),
-    "mi_unet_backward": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_uint64, C.c_int, _P]),
+    "mi_unet_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_uint64, C.c_int, _P]),
     "mi_unet_prof_enable": (C.c_int, [_P, C.c_int]),
     "mi_unet_prof_collect": (C.c_int, [_P]),
     "mi_unet_prof_reset": (C.c_int, [_P]),
     "mi_unet_step_info": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(MiStepInfo)]),
+    "mi_unet_step_output_offset": (C.c_int64, [_P, C.c_int, C.c_int]),
+    "mi_unet_step_aux_offset": (C.c_int64, [_P, C.c_int, C.c_int]),
     "mi_dice_ce_loss_fwd": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float,
                                       C.c_float, _P, _P, _P, _P]),
     "mi_dice_ce_loss_bwd": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float,

@@ -18,7 +18,7 @@ LIBDIR = HERE / "lib"
 OBJDIR = HERE / "lib" / "obj"
 LIBNAME = "libunet_mi355.so"
 SOURCES = ["igemm.hip", "norm.hip", "small.hip", "loss.hip", "ops.hip", "engine.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-munsafe-fp-atomics"]
 
 
 def _hipcc() -> str:

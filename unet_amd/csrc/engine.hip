@@ -67,6 +67,12 @@ struct Step {
         (step).rel.push_back(Reloc{offsetof(std::remove_reference<decltype(ps)>::type, field), base}); \
     } while (0)
 
+bool bases_ok(const Step& s, char* const* bases) {
+    for (const Reloc& r : s.rel)
+        if (!bases[r.base]) return false;
+    return true;
+}
+
 template <class P>
 P resolve(const Step& s, const P& src, char* const* bases) {
     P q = src;
@@ -221,7 +227,7 @@ struct Builder {
                    const Ten& sten, int S, size_t* partial_off, size_t* pbias_off, int* nslab, int* ntaps) {
         Step& s = push(u.bwd, K_WGRAD, layer);
         WgradParams& p = s.wg;
-        wgrad_geometry(cs, p);
+        wgrad_geometry(cs, u.esz, p);
         p.F = F; p.S = S; p.f0_c = f0_c;
         REL(s, p, f0, f0.base, f0.off); p.f0_pitch = f0.pitch; p.f0_coff = f0.coff;
         if (f1) { REL(s, p, f1, f1->base, f1->off); p.f1_pitch = f1->pitch; p.f1_coff = f1->coff; }
@@ -273,16 +279,18 @@ struct Builder {
         REL(s, p, dy, dy.base, dy.off); p.dy_pitch = dy.pitch; p.dy_coff = dy.coff;
         REL(s, p, out, dx.base, dx.off); p.out_pitch = dx.pitch; p.out_coff = dx.coff;
         REL(s, p, stats, B_ARENA, stats_off);
-        const size_t bs = bstats_alloc((size_t)u.nb * MI_NSLOT * c * 2 * sizeof(float));
-        const size_t da = bstats_alloc(sizeof(float));
+        const size_t bs = bstats_alloc((size_t)u.nb * MI_NSLOT * c * 2 * sizeof(double));
+        const int nda = u.nb * norm_bwd_reduce_blocks((int)u.rp[res], c);   // one slope-gradient partial per workgroup
+        const size_t da = bstats_alloc((size_t)nda * sizeof(float));
         REL(s, p, bstats, B_ARENA, bs);
         REL(s, p, dalpha, B_ARENA, da);
+        p.dalpha_slots = 1;
         REL(s, p, alpha, B_PARAMS, poff(alpha) * sizeof(float));
         p.nb = u.nb; p.npix = (int)u.rp[res]; p.c = c; p.eps = 1e-5f; p.layer = (unsigned)lid;
         const int esz = dt ? 2 : 4;
         s.kernel = c == 1 ? "norm1_bwd_kernels" : (dt ? "norm_bwd_kernels<BF16>" : "norm_bwd_kernels<F32>");
         s.work = (double)u.nb * u.rp[res] * c * esz * 5.0;
-        add_scalar_reduce(da, 1, alpha);
+        add_scalar_reduce(da, nda, alpha);
     }
 
     // statistics regions are carved from two contiguous blocks so one memset clears each
@@ -374,7 +382,7 @@ bool build(mi_unet& u) {
     // statistics blocks: reserve generously (sum over all norms), exact use tracked by cursors
     {
         size_t tot = 0;
-        for (int l = 0; l < L; ++l) tot += (size_t)(3 * R + 4) * nb * MI_NSLOT * (size_t)c[l] * 2 * sizeof(float) + 4096;
+        for (int l = 0; l < L; ++l) tot += (size_t)(3 * R + 4) * nb * MI_NSLOT * (size_t)c[l] * 2 * sizeof(double) + 4096;
         u.off_stats = B.alloc(tot); u.stats_bytes = tot;
         u.off_bstats = B.alloc(tot); u.bstats_bytes = tot;
     }
@@ -425,7 +433,7 @@ bool build(mi_unet& u) {
         D.dnA = B.new_tensor(l + 1, 2 * cout, esz);
         D.un.resize(R);
         for (int su = 0; su < R; ++su) {
-            D.un[su].stats = B.stats_alloc((size_t)nb * MI_NSLOT * cout * 2 * sizeof(float));
+            D.un[su].stats = B.stats_alloc((size_t)nb * MI_NSLOT * cout * 2 * sizeof(double));
             D.un[su].alpha = P + ".conv.unit" + std::to_string(su) + ".adn.A.weight";
             D.un[su].lid = B.layer_id++;
             D.un[su].wname = P + ".conv.unit" + std::to_string(su) + ".conv.weight";
@@ -486,7 +494,7 @@ bool build(mi_unet& u) {
         Ten in = cat[L - 2]; in.coff = 0;
         for (int su = 0; su < R; ++su) {
             UnitSave& U = bot.un[su];
-            U.stats = B.stats_alloc((size_t)nb * MI_NSLOT * cout * 2 * sizeof(float));
+            U.stats = B.stats_alloc((size_t)nb * MI_NSLOT * cout * 2 * sizeof(double));
             U.alpha = P + ".conv.unit" + std::to_string(su) + ".adn.A.weight";
             U.wname = P + ".conv.unit" + std::to_string(su) + ".conv.weight";
             U.bname = P + ".conv.unit" + std::to_string(su) + ".conv.bias";
@@ -534,8 +542,8 @@ bool build(mi_unet& u) {
         U.lidT = B.layer_id++; U.lidU = B.layer_id++;
         if (l > 0) {
             U.rawT = B.new_tensor(l, outc, esz); U.actT = B.new_tensor(l, outc, esz); U.rawU = B.new_tensor(l, outc, esz);
-            U.statsT = B.stats_alloc((size_t)nb * MI_NSLOT * outc * 2 * sizeof(float));
-            U.statsU = B.stats_alloc((size_t)nb * MI_NSLOT * outc * 2 * sizeof(float));
+            U.statsT = B.stats_alloc((size_t)nb * MI_NSLOT * outc * 2 * sizeof(double));
+            U.statsU = B.stats_alloc((size_t)nb * MI_NSLOT * outc * 2 * sizeof(double));
             ConvShape ct = B.shape(1, 3, 2, K, outc, l + 1);
             U.wT_f = B.packed_alloc(KK, outc, K);
             if (!B.add_igemm(u.fwd, lname + ".convT", ct, DIR_FWD, cat[l], K, nullptr, K, outc, U.wT_f, nullptr, 0, U.rawT,
@@ -554,7 +562,7 @@ bool build(mi_unet& u) {
                            &U.actT, out, U.lidU);
         } else {
             U.rawT = B.new_tensor(0, 1, 4); U.actT = B.new_tensor(0, 1, 4);
-            U.statsT = B.stats_alloc((size_t)nb * MI_NSLOT * 2 * sizeof(float));
+            U.statsT = B.stats_alloc((size_t)nb * MI_NSLOT * 2 * sizeof(double));
             {
                 Step& s = B.push(u.fwd, K_C1_T, lname + ".convT (2C->1)");
                 C1Params& p = s.c1;
@@ -881,6 +889,7 @@ int upload_tables(mi_unet& u, char* const* bases, bool want_reduce, hipStream_t 
 }
 
 int run_step(mi_unet& u, Step& s, char* const* bases, int training, uint64_t seed, hipStream_t st) {
+    if (!bases_ok(s, bases)) { mi_set_error("step '" + s.layer + "' needs a buffer the caller did not pass"); return -1; }
     switch (s.kind) {
         case K_IGEMM: return launch_igemm(s.dtype, resolve(s, s.ig, bases), st);
         case K_WGRAD: return launch_wgrad(s.dtype, resolve(s, s.wg, bases), st);
@@ -1024,17 +1033,49 @@ int mi_unet_forward(mi_unet* u, const float* params, const float* x, float* logi
     return run_list(*u, u->fwd, 0, -1, bases, training, seed, st);
 }
 
-int mi_unet_backward(mi_unet* u, const float* params, const float* dlogits, float* grads, void* workspace, int training,
-                     uint64_t seed, int bucket, void* stream) {
-    MI_CHECK(u && params && dlogits && grads && workspace, "null argument");
+int mi_unet_backward(mi_unet* u, const float* params, const float* x, const float* dlogits, float* grads, void* workspace,
+                     int training, uint64_t seed, int bucket, void* stream) {
+    MI_CHECK(u && params && x && dlogits && grads && workspace, "null argument");
     MI_CHECK(u->cfg.with_backward, "plan was created without a backward pass");
     MI_CHECK(bucket < 3, "bucket must be < 3");
     char* bases[B_NBASE] = {nullptr};
     bases[B_ARENA] = (char*)workspace; bases[B_PARAMS] = (char*)params; bases[B_GRADS] = (char*)grads;
-    bases[B_DLOGITS] = (char*)dlogits;
+    bases[B_DLOGITS] = (char*)dlogits; bases[B_XIN] = (char*)x;
     hipStream_t st = (hipStream_t)stream;
     if (int r = upload_tables(*u, bases, true, st)) return r;
     return run_list(*u, u->bwd, 1, bucket, bases, training, seed, st);
+}
+
+// debug aid: arena offset of the tensor each step writes (-1 when it writes outside the arena)
+int64_t mi_unet_step_output_offset(const mi_unet* u, int backward, int i) {
+    const std::vector<Step>& l = backward ? u->bwd : u->fwd;
+    if (i < 0 || i >= (int)l.size()) return -1;
+    const Step& s = l[i];
+    auto arena_field = [&](size_t off) {
+        for (const Reloc& r : s.rel) if (r.field_off == off && r.base == B_ARENA) return true;
+        return false;
+    };
+    switch (s.kind) {
+        case K_IGEMM: return arena_field(offsetof(IgemmParams, out)) ? (int64_t)(uintptr_t)s.ig.out : -1;
+        case K_NORM_FWD: case K_NORM_BWD: return arena_field(offsetof(NormParams, out)) ? (int64_t)(uintptr_t)s.nm.out : -1;
+        case K_C1_FWD: return arena_field(offsetof(C1Params, y_out)) ? (int64_t)(uintptr_t)s.c1.y_out : -1;
+        case K_C1_T: return arena_field(offsetof(C1Params, x1_out)) ? (int64_t)(uintptr_t)s.c1.x1_out : -1;
+        case K_STENCIL: return arena_field(offsetof(StencilParams, out)) ? (int64_t)(uintptr_t)s.stn.out : -1;
+        case K_WGRAD: return (int64_t)(uintptr_t)s.wg.partial;
+        case K_C1_WGRAD: return (int64_t)(uintptr_t)s.c1.partial;
+        case K_STENCIL_WGRAD: return (int64_t)(uintptr_t)s.stn.partial;
+        default: return -1;
+    }
+}
+
+// debug aid: arena offset of the backward-statistics block of a norm backward step (-1 otherwise)
+int64_t mi_unet_step_aux_offset(const mi_unet* u, int backward, int i) {
+    const std::vector<Step>& l = backward ? u->bwd : u->fwd;
+    if (i < 0 || i >= (int)l.size()) return -1;
+    const Step& s = l[i];
+    if (s.kind == K_NORM_BWD) return (int64_t)(uintptr_t)s.nm.bstats;
+    if (s.kind == K_NORM_FWD) return (int64_t)(uintptr_t)s.nm.stats;
+    return -1;
 }
 
 int mi_unet_prof_enable(mi_unet* u, int on) { u->prof = on != 0; return 0; }
@@ -1071,7 +1112,7 @@ int mi_unet_step_info(const mi_unet* u, int backward, int i, mi_step_info* info)
 
 // ---------------- loss / metric / optimizer / sliding window ----------------
 int mi_dice_ce_loss_fwd(const float* logits, const void* target, int target_dtype, int fold2, int nb, int64_t npix,
-                        float smooth_nr, float smooth_dr, float lambda_dice, float lambda_ce, float* sums, float* loss,
+                        float smooth_nr, float smooth_dr, float lambda_dice, float lambda_ce, double* sums, float* loss,
                         float* loss_accum, void* stream) {
     MI_CHECK(logits && target && sums && loss, "null argument");
     MI_CHECK(npix > 0 && npix < 2147483647LL && nb > 0, "bad sizes");
@@ -1083,12 +1124,12 @@ int mi_dice_ce_loss_fwd(const float* logits, const void* target, int target_dtyp
 }
 
 int mi_dice_ce_loss_bwd(const float* logits, const void* target, int target_dtype, int fold2, int nb, int64_t npix,
-                        float smooth_nr, float smooth_dr, float lambda_dice, float lambda_ce, const float* sums,
+                        float smooth_nr, float smooth_dr, float lambda_dice, float lambda_ce, const double* sums,
                         const float* grad_out, float grad_scale, float* dlogits, void* stream) {
     MI_CHECK(logits && target && sums && dlogits, "null argument");
     MI_CHECK(npix > 0 && npix < 2147483647LL && nb > 0, "bad sizes");
     LossParams p; memset(&p, 0, sizeof(p));
-    p.logits = logits; p.target = target; p.tdtype = target_dtype; p.fold2 = fold2; p.sums = const_cast<float*>(sums);
+    p.logits = logits; p.target = target; p.tdtype = target_dtype; p.fold2 = fold2; p.sums = const_cast<double*>(sums);
     p.dlogits = dlogits; p.gout = grad_out; p.gscale = grad_scale; p.nb = nb; p.npix = (int)npix;
     p.smooth_nr = smooth_nr; p.smooth_dr = smooth_dr; p.lambda_dice = lambda_dice; p.lambda_ce = lambda_ce;
     return launch_loss_bwd(p, (hipStream_t)stream);

@@ -30,16 +30,27 @@ inline void conv_out_dims(const ConvShape& s, int od[3]) {
 
 inline int ceil_log2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
-// 256 base pixels per tile, power-of-two extents, as square as the grid allows
-inline void choose_tile(int ndim, const int bd[3], int tlog[3]) {
-    if (ndim == 2) {
-        int lx = ceil_log2(bd[2]); if (lx > 4) lx = 4;
-        tlog[0] = 0; tlog[2] = lx; tlog[1] = 8 - lx;
-    } else {
-        int lx = ceil_log2(bd[2]); if (lx > 3) lx = 3;
-        int ly = ceil_log2(bd[1]); if (ly > 3) ly = 3;
-        tlog[2] = lx; tlog[1] = ly; tlog[0] = 8 - lx - ly;
-    }
+// 256 base pixels per tile with power-of-two extents: the shape that stages the fewest LDS patch
+// pixels over the whole grid (tiles x patch volume), subject to the patch fitting `max_pp` pixels.
+// `sa` is the gather stride, halo[d] the tap extent (omax - omin) per dim.
+inline void choose_tile(int ndim, const int bd[3], int sa, const int halo[3], long max_pp, int tlog[3]) {
+    double best = -1.0;
+    int bl[3] = {0, 4, 4};
+    for (int lz = 0; lz <= (ndim == 3 ? 8 : 0); ++lz)
+        for (int ly = 0; ly + lz <= 8; ++ly) {
+            const int lx = 8 - lz - ly;
+            const int l[3] = {lz, ly, lx};
+            double tiles = 1.0, pp = 1.0;
+            for (int d = 0; d < 3; ++d) {
+                const int T = 1 << l[d];
+                tiles *= (bd[d] + T - 1) / T;
+                pp *= (double)(T - 1) * sa + halo[d] + 1;
+            }
+            if (pp > (double)max_pp) continue;
+            const double cost = tiles * pp - 1e-3 * lx;  // ties: the widest x extent (coalescing)
+            if (best < 0 || cost < best) { best = cost; bl[0] = lz; bl[1] = ly; bl[2] = lx; }
+        }
+    tlog[0] = bl[0]; tlog[1] = bl[1]; tlog[2] = bl[2];
 }
 
 struct TapList {
@@ -137,14 +148,15 @@ inline bool igemm_geometry(const ConvShape& s, int dir, IgemmParams& p, int kidx
     }
     (void)phase;
     p.nb = s.nb;
-    choose_tile(s.ndim, p.bd, p.tlog);
-    int omax[3];
+    int omax[3], halo[3];
     for (int d = 0; d < 3; ++d) { p.omin[d] = 0; omax[d] = 0; }
     for (int i = 0; i < t.n; ++i)
         for (int d = 0; d < 3; ++d) {
             if (t.off[i][d] < p.omin[d]) p.omin[d] = t.off[i][d];
             if (t.off[i][d] > omax[d]) omax[d] = t.off[i][d];
         }
+    for (int d = 0; d < 3; ++d) halo[d] = omax[d] - p.omin[d];
+    choose_tile(s.ndim, p.bd, p.sa, halo, 2900, p.tlog);
     for (int d = 0; d < 3; ++d) {
         const int T = 1 << p.tlog[d];
         p.ntile[d] = (p.bd[d] + T - 1) / T;
@@ -171,7 +183,7 @@ inline bool igemm_geometry(const ConvShape& s, int dir, IgemmParams& p, int kidx
 
 // Geometric part of a weight-gradient launch.  Convolution: F = dy, S = x (stride = conv
 // stride).  Transposed convolution: F = x, S = dy (stride 2).
-inline void wgrad_geometry(const ConvShape& s, WgradParams& p) {
+inline void wgrad_geometry(const ConvShape& s, int esz, WgradParams& p) {
     int od[3];
     conv_out_dims(s, od);
     for (int d = 0; d < 3; ++d) {
@@ -180,8 +192,12 @@ inline void wgrad_geometry(const ConvShape& s, WgradParams& p) {
     }
     p.ss = s.transposed ? 2 : s.stride;
     p.nb = s.nb;
-    choose_tile(s.ndim, p.bd, p.tlog);
     const int kz = kext(s, 0), ky = kext(s, 1), kx = kext(s, 2);
+    {
+        const int halo[3] = {0, ky - 1, kx - 1};  // one kz plane per tap group: no z halo
+        const long row = 16 * esz + 16;           // smallest LDS row (16 channels)
+        choose_tile(s.ndim, p.bd, p.ss, halo, (150 * 1024 - 256 * row) / row, p.tlog);
+    }
     const int pz = (kz - 1) / 2, py = (ky - 1) / 2, px = (kx - 1) / 2;
     p.ntapg = kz;
     for (int g = 0; g < 3; ++g) p.tg_zoff[g] = (g < kz) ? g - pz : 0;

@@ -211,10 +211,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         }
     }
     if (do_stats) {
+        // fixed-order reduction inside the workgroup (16-lane shuffle tree, then the four waves in
+        // order); the per-workgroup sums are added to fp64 accumulators, so the result does not
+        // depend on the order in which workgroups arrive (to fp32 rounding)
         __syncthreads();
-        float* sst = reinterpret_cast<float*>(smem);  // [NT][2]
-        for (int i = tid; i < NT * 2; i += 256) sst[i] = 0.f;
-        __syncthreads();
+        float* sst = reinterpret_cast<float*>(smem);  // [4 waves][NT][2]
 #pragma unroll
         for (int nf = 0; nf < NFRAG; ++nf)
 #pragma unroll
@@ -224,15 +225,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
                 for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
                 if (lr == 0) {
                     const int cl = chan_of_row<NFRAG>(nf, 4 * g + j);
-                    atomicAdd(&sst[cl * 2], a);
-                    atomicAdd(&sst[cl * 2 + 1], b);
+                    sst[(wave * NT + cl) * 2] = a;
+                    sst[(wave * NT + cl) * 2 + 1] = b;
                 }
             }
         __syncthreads();
         for (int i = tid; i < NT * 2; i += 256) {
             const int ch = n0 + (i >> 1);
-            if (ch < p.nstat)
-                atomicAdd(&p.stats[(((size_t)img * MI_NSLOT + slot) * p.stats_c + ch) * 2 + (i & 1)], sst[i]);
+            if (ch < p.nstat) {
+                const float v = ((sst[i] + sst[NT * 2 + i]) + sst[2 * NT * 2 + i]) + sst[3 * NT * 2 + i];
+                atomicAdd(&p.stats[(((size_t)img * MI_NSLOT + slot) * p.stats_c + ch) * 2 + (i & 1)], (double)v);
+            }
         }
     }
 }
@@ -497,7 +500,7 @@ int launch_igemm_t(const IgemmParams& p, hipStream_t st) {
     const int PP = p.pd[0] * p.pd[1] * p.pd[2];
     const int tapg_pad = (CPS == 2) ? ((p.tapg + 1) & ~1) : p.tapg;
     size_t lds = (size_t)PP * PITCH + (size_t)tapg_pad * NFRAG * 16 * PITCH;
-    if (lds < (size_t)NFRAG * 16 * 2 * 4) lds = NFRAG * 16 * 2 * 4;
+    if (lds < (size_t)NFRAG * 16 * 2 * 4 * 4) lds = NFRAG * 16 * 2 * 4 * 4;
     auto kern = igemm_kernel<TR, CPS, NFRAG>;
     if (int r = set_lds(kern, lds)) return r;
     dim3 grid(p.nb * p.ntile[0] * p.ntile[1] * p.ntile[2], p.N / (NFRAG * 16), p.nphase);

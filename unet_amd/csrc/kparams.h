@@ -20,7 +20,7 @@ struct IgemmParams {
     const float* bias; int bias_c0;         // bias[ch-bias_c0] is added to output channels >= bias_c0 (null: none)
     char* out; int out_pitch, out_coff, N;
     const char* addend; int add_pitch, add_coff;  // optional tensor added in the epilogue (may alias out)
-    float* stats; int stats_c, nstat;       // per-(image,slot,channel) {sum, sum of squares} of the first nstat channels
+    double* stats; int stats_c, nstat;      // per-(image,slot,channel) {sum, sum of squares} of the first nstat channels
     int nb;
     int id[3], od[3], bd[3];                // gathered-tensor dims, output dims, base-grid dims (z,y,x)
     int sa, so;
@@ -75,10 +75,11 @@ struct NormParams {
     const char* dy; int dy_pitch, dy_coff;  // backward: gradient of the activated output
     const char* res; int res_pitch, res_coff;  // forward: optional residual added after the activation
     char* out; int out_pitch, out_coff;     // forward: activated output; backward: gradient of x
-    const float* stats;                     // forward statistics [nb][NSLOT][c][2]
-    float* bstats;                          // backward statistics [nb][NSLOT][c][2]
+    const double* stats;                    // forward statistics [nb][NSLOT][c][2] (fp64 accumulators)
+    double* bstats;                         // backward statistics [nb][NSLOT][c][2]
     const float* alpha;                     // PReLU slope (device scalar)
-    float* dalpha;                          // gradient of the slope (device scalar, accumulated)
+    float* dalpha;                          // gradient of the slope: accumulated scalar, or per-workgroup partials
+    int dalpha_slots;                       // 0: atomicAdd into dalpha[0]; 1: dalpha[img*gridDim.x + blockIdx.x] = partial
     int nb, npix, c;
     float eps;
     unsigned long long seed; unsigned layer, drop_thresh; float drop_scale;  // drop_thresh==0: no dropout
@@ -95,7 +96,7 @@ struct C1Params {
     int y_pitch, y_coff, N;
     const float* w; const float* w2; int n_w1;  // weights [n][KK]; channels >= n_w1 read w2[(n-n_w1)][KK]
     const float* bias; int bias_c0;
-    float* stats; int stats_c, nstat;
+    double* stats; int stats_c, nstat;
     int ndim, nb;
     int fd[3], cd[3];
     float* partial; float* partial_bias;    // weight-gradient slabs [slab][KK][N], [slab][N]
@@ -120,6 +121,7 @@ int launch_reduce_one(const ReduceDesc& d, hipStream_t st);
 int launch_pack_one(int dtype, const PackDesc& d, hipStream_t st);
 int launch_norm_fwd(int dtype, const NormParams& p, hipStream_t st);
 int launch_norm_bwd(int dtype, const NormParams& p, hipStream_t st);
+int norm_bwd_reduce_blocks(int npix, int c);   // workgroups per image of the backward reduction
 int launch_c1_s2_fwd(int dtype, const C1Params& p, hipStream_t st);
 int launch_c1_s2_T(int dtype, const C1Params& p, hipStream_t st);
 int launch_c1_s2_wgrad(int dtype, const C1Params& p, hipStream_t st);

@@ -39,19 +39,19 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const LossParams p) {
     __syncthreads();
     if (threadIdx.x < 4)
         atomicAdd(&p.sums[b * 4 + threadIdx.x],
-                  red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+                  (double)(((red[threadIdx.x][0] + red[threadIdx.x][1]) + red[threadIdx.x][2]) + red[threadIdx.x][3]));
 }
 
 // loss = lambda_dice * mean_b(1 - (2I+snr)/(P+T+sdr)) + lambda_ce * sum_b(bce) / (nb*npix)
 __global__ void loss_finalize_kernel(const LossParams p) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    float dice = 0.f, ce = 0.f;
+    double dice = 0.0, ce = 0.0;
     for (int b = 0; b < p.nb; ++b) {
-        const float* s = p.sums + b * 4;
-        dice += 1.f - (2.f * s[0] + p.smooth_nr) / (s[1] + s[2] + p.smooth_dr);
+        const double* s = p.sums + b * 4;
+        dice += 1.0 - (2.0 * s[0] + (double)p.smooth_nr) / (s[1] + s[2] + (double)p.smooth_dr);
         ce += s[3];
     }
-    const float l = p.lambda_dice * dice / (float)p.nb + p.lambda_ce * ce / ((float)p.nb * (float)p.npix);
+    const float l = (float)((double)p.lambda_dice * dice / (double)p.nb + (double)p.lambda_ce * ce / ((double)p.nb * (double)p.npix));
     p.loss[0] = l;
     if (p.loss_accum) p.loss_accum[0] += l;
 }
@@ -62,9 +62,9 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const LossParams p) {
     const float* z = p.logits + (size_t)b * p.npix;
     float* dz = p.dlogits + (size_t)b * p.npix;
     const float g = (p.gout ? p.gout[0] : 1.f) * p.gscale;
-    const float* sm = p.sums + b * 4;
-    const float D = sm[1] + sm[2] + p.smooth_dr;
-    const float num = 2.f * sm[0] + p.smooth_nr;
+    const double* sm = p.sums + b * 4;
+    const float D = (float)(sm[1] + sm[2] + (double)p.smooth_dr);
+    const float num = (float)(2.0 * sm[0] + (double)p.smooth_nr);
     const float cd = g * p.lambda_dice / ((float)p.nb * D * D);
     const float cc = g * p.lambda_ce / ((float)p.nb * (float)p.npix);
     for (int i = blockIdx.x * 256 + threadIdx.x; i < p.npix; i += gridDim.x * 256) {
@@ -219,9 +219,9 @@ int grid_for(long long n, int per_block, int cap) {
 
 }  // namespace
 
-// sums ([nb][4] floats) is zeroed here, then filled; loss[0] is written; loss_accum (optional) is accumulated.
+// sums ([nb][4] doubles) is zeroed here, then filled; loss[0] is written; loss_accum (optional) is accumulated.
 int launch_loss_fwd(const LossParams& p, hipStream_t st) {
-    MI_HIP(hipMemsetAsync(p.sums, 0, (size_t)p.nb * 4 * sizeof(float), st));
+    MI_HIP(hipMemsetAsync(p.sums, 0, (size_t)p.nb * 4 * sizeof(double), st));
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(grid_for(p.npix, 2048, 128), p.nb), dim3(256), 0, st, p);
     if (int r = check_launch("loss_reduce")) return r;
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, p);

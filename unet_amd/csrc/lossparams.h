@@ -6,7 +6,7 @@
 struct LossParams {
     const float* logits;        // [nb][npix] fp32 (one channel)
     const void* target; int tdtype; int fold2;   // fold2: label value 2 counts as 1
-    float* sums;                // [nb][4] = { sum p*t, sum p, sum t, sum bce }
+    double* sums;               // [nb][4] = { sum p*t, sum p, sum t, sum bce } (fp64 accumulators)
     float* loss; float* loss_accum;
     float* dlogits; const float* gout; float gscale;
     int nb, npix;

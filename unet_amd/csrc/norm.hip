@@ -11,21 +11,20 @@
 
 namespace {
 
-// mean / rstd of every channel of image `img` into LDS (2 floats per channel)
-__device__ __forceinline__ void load_moments(const float* stats, int img, int c, int npix, float eps, float* sm) {
+// mean / rstd of every channel of image `img` into LDS (2 floats per channel); the sums are fp64
+__device__ __forceinline__ void load_moments(const double* stats, int img, int c, int npix, float eps, float* sm) {
     for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
-        float s1 = 0.f, s2 = 0.f;
+        double s1 = 0.0, s2 = 0.0;
 #pragma unroll
         for (int sl = 0; sl < MI_NSLOT; ++sl) {
-            const float* q = stats + (((size_t)img * MI_NSLOT + sl) * c + ch) * 2;
+            const double* q = stats + (((size_t)img * MI_NSLOT + sl) * c + ch) * 2;
             s1 += q[0]; s2 += q[1];
         }
-        const float inv = 1.0f / (float)npix;
-        const float mean = s1 * inv;
-        float var = s2 * inv - mean * mean;
-        var = var > 0.f ? var : 0.f;
-        sm[ch * 2] = mean;
-        sm[ch * 2 + 1] = rsqrtf(var + eps);
+        const double mean = s1 / (double)npix;
+        double var = s2 / (double)npix - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        sm[ch * 2] = (float)mean;
+        sm[ch * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
     }
 }
 
@@ -67,20 +66,21 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const NormParams p) {
     }
 }
 
-// backward pass 1: per-(image, channel) sums of gh and gh*xh, and the slope gradient
+// backward pass 1: per-(image, channel) sums of gh and gh*xh, and the slope gradient.
+// Reduction order is fixed inside a workgroup (per-thread partials in LDS, summed row by row);
+// workgroup sums go to fp64 accumulators.
 template <class TR>
 __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const NormParams p) {
     constexpr int VEC = TR::VEC, ESZ = TR::ESZ;
-    extern __shared__ __attribute__((aligned(16))) float sm[];  // [c][2] moments, then [c][2] accumulators
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // [c][2] moments, then [256][2*VEC] partials
+    __shared__ float red_da[4];
     const int img = blockIdx.y;
-    float* acc = sm + 2 * p.c;
+    float* part = sm + 2 * p.c;
     load_moments(p.stats, img, p.c, p.npix, p.eps, sm);
-    for (int i = threadIdx.x; i < 2 * p.c; i += 256) acc[i] = 0.f;
     __syncthreads();
     const float alpha = *p.alpha;
     const int cv_n = p.c / VEC;
-    // a thread keeps one channel vector and walks pixels
-    const int rows = 256 / cv_n > 0 ? 256 / cv_n : 1;   // pixel rows handled per sweep
+    const int rows = 256 / cv_n;   // pixel rows handled per sweep (cv_n <= 256 is checked by the launcher)
     const int cv = threadIdx.x % cv_n, prow = threadIdx.x / cv_n;
     const int ch0 = cv * VEC;
     const int pix_per_block = (p.npix + gridDim.x - 1) / gridDim.x;
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const NormParams p
     float s1[VEC], s2[VEC], da = 0.f;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
-    if (prow < rows && cv_n <= 256) {
+    if (prow < rows) {
         for (int pix = pbeg + prow; pix < pend; pix += rows) {
             const size_t gp = (size_t)img * p.npix + pix;
             float x[VEC], dy[VEC];
@@ -111,18 +111,28 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const NormParams p
                 s1[e] += gh; s2[e] += gh * xh;
             }
         }
+    }
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            atomicAdd(&acc[(ch0 + e) * 2], s1[e]);
-            atomicAdd(&acc[(ch0 + e) * 2 + 1], s2[e]);
-        }
+    for (int e = 0; e < VEC; ++e) {
+        part[threadIdx.x * 2 * VEC + e] = s1[e];
+        part[threadIdx.x * 2 * VEC + VEC + e] = s2[e];
     }
     da = wave_sum(da);
+    if ((threadIdx.x & 63) == 0) red_da[threadIdx.x >> 6] = da;
     __syncthreads();
     const int slot = blockIdx.x % MI_NSLOT;
-    for (int i = threadIdx.x; i < 2 * p.c; i += 256)
-        atomicAdd(&p.bstats[(((size_t)img * MI_NSLOT + slot) * p.c) * 2 + i], acc[i]);
-    if ((threadIdx.x & 63) == 0 && p.dalpha) atomicAdd(p.dalpha, da);
+    for (int i = threadIdx.x; i < 2 * p.c; i += 256) {
+        const int ch = i >> 1, k = i & 1;
+        const int ccv = ch / VEC, e = ch - ccv * VEC;
+        float a = 0.f;
+        for (int r = 0; r < rows; ++r) a += part[(r * cv_n + ccv) * 2 * VEC + k * VEC + e];
+        atomicAdd(&p.bstats[(((size_t)img * MI_NSLOT + slot) * p.c) * 2 + i], (double)a);
+    }
+    if (threadIdx.x == 0 && p.dalpha) {
+        const float v = ((red_da[0] + red_da[1]) + red_da[2]) + red_da[3];
+        if (p.dalpha_slots) p.dalpha[img * gridDim.x + blockIdx.x] = v;
+        else atomicAdd(p.dalpha, v);
+    }
 }
 
 // backward pass 2: dx
@@ -134,10 +144,10 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const NormParams p)
     float* bm = sm + 2 * p.c;
     load_moments(p.stats, img, p.c, p.npix, p.eps, sm);
     for (int i = threadIdx.x; i < 2 * p.c; i += 256) {
-        float a = 0.f;
+        double a = 0.0;
 #pragma unroll
         for (int sl = 0; sl < MI_NSLOT; ++sl) a += p.bstats[(((size_t)img * MI_NSLOT + sl) * p.c) * 2 + i];
-        bm[i] = a / (float)p.npix;
+        bm[i] = (float)(a / (double)p.npix);
     }
     __syncthreads();
     const float alpha = *p.alpha;
@@ -173,17 +183,18 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const NormParams p)
 
 // ---- one-channel fp32 planar variants (top of the decoder) ------------------------
 // tensors are [nb][npix] fp32; four consecutive pixels per lane.
-__device__ __forceinline__ void c1_moments(const float* stats, int img, int npix, float eps, float& mean, float& rstd) {
-    float s1 = 0.f, s2 = 0.f;
+__device__ __forceinline__ void c1_moments(const double* stats, int img, int npix, float eps, float& mean, float& rstd) {
+    double s1 = 0.0, s2 = 0.0;
 #pragma unroll
     for (int sl = 0; sl < MI_NSLOT; ++sl) {
         s1 += stats[((size_t)img * MI_NSLOT + sl) * 2];
         s2 += stats[((size_t)img * MI_NSLOT + sl) * 2 + 1];
     }
-    mean = s1 / (float)npix;
-    float var = s2 / (float)npix - mean * mean;
-    var = var > 0.f ? var : 0.f;
-    rstd = rsqrtf(var + eps);
+    const double m = s1 / (double)npix;
+    double var = s2 / (double)npix - m * m;
+    var = var > 0.0 ? var : 0.0;
+    mean = (float)m;
+    rstd = (float)(1.0 / sqrt(var + (double)eps));
 }
 
 __global__ __launch_bounds__(256) void norm1_fwd_kernel(const NormParams p) {
@@ -231,9 +242,13 @@ __global__ __launch_bounds__(256) void norm1_bwd_reduce_kernel(const NormParams 
     __syncthreads();
     if (threadIdx.x == 0) {
         const int slot = blockIdx.x % MI_NSLOT;
-        atomicAdd(&p.bstats[((size_t)img * MI_NSLOT + slot) * 2], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-        atomicAdd(&p.bstats[((size_t)img * MI_NSLOT + slot) * 2 + 1], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
-        if (p.dalpha) atomicAdd(p.dalpha, red[2][0] + red[2][1] + red[2][2] + red[2][3]);
+        atomicAdd(&p.bstats[((size_t)img * MI_NSLOT + slot) * 2], (double)(((red[0][0] + red[0][1]) + red[0][2]) + red[0][3]));
+        atomicAdd(&p.bstats[((size_t)img * MI_NSLOT + slot) * 2 + 1], (double)(((red[1][0] + red[1][1]) + red[1][2]) + red[1][3]));
+        if (p.dalpha) {
+            const float v = ((red[2][0] + red[2][1]) + red[2][2]) + red[2][3];
+            if (p.dalpha_slots) p.dalpha[img * gridDim.x + blockIdx.x] = v;
+            else atomicAdd(p.dalpha, v);
+        }
     }
 }
 
@@ -241,13 +256,13 @@ __global__ __launch_bounds__(256) void norm1_bwd_apply_kernel(const NormParams p
     const int img = blockIdx.y;
     float mean, rstd;
     c1_moments(p.stats, img, p.npix, p.eps, mean, rstd);
-    float b1 = 0.f, b2 = 0.f;
+    double d1 = 0.0, d2 = 0.0;
 #pragma unroll
     for (int sl = 0; sl < MI_NSLOT; ++sl) {
-        b1 += p.bstats[((size_t)img * MI_NSLOT + sl) * 2];
-        b2 += p.bstats[((size_t)img * MI_NSLOT + sl) * 2 + 1];
+        d1 += p.bstats[((size_t)img * MI_NSLOT + sl) * 2];
+        d2 += p.bstats[((size_t)img * MI_NSLOT + sl) * 2 + 1];
     }
-    b1 /= (float)p.npix; b2 /= (float)p.npix;
+    const float b1 = (float)(d1 / (double)p.npix), b2 = (float)(d2 / (double)p.npix);
     const float alpha = *p.alpha;
     const float* x = reinterpret_cast<const float*>(p.x) + (size_t)img * p.npix;
     const float* dy = reinterpret_cast<const float*>(p.dy) + (size_t)img * p.npix;
@@ -273,6 +288,14 @@ int check_launch(const char* what) {
 
 }  // namespace
 
+int norm_bwd_reduce_blocks(int npix, int c) {
+    int g = (npix + 2047) / 2048;
+    const int cap = c == 1 ? 128 : 256;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return g;
+}
+
 // dtype: 0 fp32, 1 bf16.  c == 1 selects the planar fp32 kernels (pitch must be 1, dtype 0).
 int launch_norm_fwd(int dtype, const NormParams& p, hipStream_t st) {
     if (p.c == 1) {
@@ -291,11 +314,11 @@ int launch_norm_fwd(int dtype, const NormParams& p, hipStream_t st) {
     return check_launch("norm_fwd");
 }
 
-// bstats ([nb][NSLOT][c][2] floats) must be zero on entry; dalpha is accumulated into.
+// bstats ([nb][NSLOT][c][2] doubles) must be zero on entry; dalpha is accumulated into.
 int launch_norm_bwd(int dtype, const NormParams& p, hipStream_t st) {
     if (p.c == 1) {
         MI_CHECK(dtype == 0 && p.x_pitch == 1 && p.out_pitch == 1 && p.dy_pitch == 1, "one-channel tensors are planar fp32");
-        int gx = (p.npix + 2047) / 2048; if (gx > 128) gx = 128;
+        const int gx = norm_bwd_reduce_blocks(p.npix, 1);
         hipLaunchKernelGGL(norm1_bwd_reduce_kernel, dim3(gx, p.nb), dim3(256), 0, st, p);
         if (int r = check_launch("norm1_bwd_reduce")) return r;
         int ga = (p.npix + 1023) / 1024; if (ga > 256) ga = 256;
@@ -306,9 +329,10 @@ int launch_norm_bwd(int dtype, const NormParams& p, hipStream_t st) {
     MI_CHECK(p.c % vec == 0, "channels must be a multiple of the 16-byte vector");
     MI_CHECK(p.c / vec <= 256, "too many channels for the reduction kernel");
     const size_t lds = (size_t)p.c * 4 * sizeof(float);
-    int gr = (p.npix + 2047) / 2048; if (gr < 1) gr = 1; if (gr > 256) gr = 256;
-    if (dtype) hipLaunchKernelGGL(norm_bwd_reduce_kernel<BF16>, dim3(gr, p.nb), dim3(256), lds, st, p);
-    else hipLaunchKernelGGL(norm_bwd_reduce_kernel<F32>, dim3(gr, p.nb), dim3(256), lds, st, p);
+    const size_t lds_r = ((size_t)p.c * 2 + 256 * 2 * vec) * sizeof(float);
+    const int gr = norm_bwd_reduce_blocks(p.npix, p.c);
+    if (dtype) hipLaunchKernelGGL(norm_bwd_reduce_kernel<BF16>, dim3(gr, p.nb), dim3(256), lds_r, st, p);
+    else hipLaunchKernelGGL(norm_bwd_reduce_kernel<F32>, dim3(gr, p.nb), dim3(256), lds_r, st, p);
     if (int r = check_launch("norm_bwd_reduce")) return r;
     const long long nvec = (long long)p.npix * (p.c / vec);
     const int gx = (int)((nvec + 256 * NORM_ITEMS - 1) / (256 * NORM_ITEMS));

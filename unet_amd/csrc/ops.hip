@@ -62,7 +62,7 @@ int mi_conv_pack(const mi_conv_desc* d, int dgrad, const float* w, void* packed,
 }
 
 static int run_igemm(const mi_conv_desc* d, int dir, const mi_tensor* in, const void* packed, const float* bias,
-                     const mi_tensor* out, const mi_tensor* addend, float* stats, void* stream) {
+                     const mi_tensor* out, const mi_tensor* addend, double* stats, void* stream) {
     if (int r = check_desc(d)) return r;
     MI_CHECK(in && in->ptr && packed && out && out->ptr, "null argument");
     const ConvShape s = to_shape(d);
@@ -81,7 +81,7 @@ static int run_igemm(const mi_conv_desc* d, int dir, const mi_tensor* in, const 
 }
 
 int mi_conv_forward(const mi_conv_desc* d, const mi_tensor* x, const void* packed, const float* bias, const mi_tensor* y,
-                    const mi_tensor* addend, float* stats, void* stream) {
+                    const mi_tensor* addend, double* stats, void* stream) {
     return run_igemm(d, DIR_FWD, x, packed, bias, y, addend, stats, stream);
 }
 
@@ -93,7 +93,7 @@ int mi_conv_dgrad(const mi_conv_desc* d, const mi_tensor* dy, const void* packed
 static void wgrad_params(const mi_conv_desc* d, WgradParams& p) {
     const ConvShape s = to_shape(d);
     memset(&p, 0, sizeof(p));
-    wgrad_geometry(s, p);
+    wgrad_geometry(s, d->dtype ? 2 : 4, p);
     p.F = d->transposed ? d->cin : d->cout;
     p.S = d->transposed ? d->cout : d->cin;
     p.f0_c = p.F;
@@ -147,7 +147,7 @@ static void fill_drop(NormParams& p, float dropout, uint64_t seed, uint32_t laye
     } else { p.drop_thresh = 0; p.drop_scale = 1.f; }
 }
 
-int mi_instnorm_prelu_fwd(int dtype, int nb, int64_t npix, int c, const mi_tensor* raw, const float* stats,
+int mi_instnorm_prelu_fwd(int dtype, int nb, int64_t npix, int c, const mi_tensor* raw, const double* stats,
                           const float* alpha, const mi_tensor* res, const mi_tensor* out, float dropout, uint64_t seed,
                           uint32_t layer, void* stream) {
     MI_CHECK(raw && raw->ptr && stats && alpha && out && out->ptr, "null argument");
@@ -162,7 +162,7 @@ int mi_instnorm_prelu_fwd(int dtype, int nb, int64_t npix, int c, const mi_tenso
 }
 
 int mi_instnorm_prelu_bwd(int dtype, int nb, int64_t npix, int c, const mi_tensor* dy, const mi_tensor* raw,
-                          const float* stats, const float* alpha, float* bstats, float* dalpha, const mi_tensor* dx,
+                          const double* stats, const float* alpha, double* bstats, float* dalpha, const mi_tensor* dx,
                           float dropout, uint64_t seed, uint32_t layer, void* stream) {
     MI_CHECK(raw && raw->ptr && dy && dy->ptr && stats && alpha && bstats && dx && dx->ptr, "null argument");
     MI_CHECK(npix > 0 && npix < 2147483647LL, "bad pixel count");
@@ -173,7 +173,7 @@ int mi_instnorm_prelu_bwd(int dtype, int nb, int64_t npix, int c, const mi_tenso
     p.stats = stats; p.bstats = bstats; p.alpha = alpha; p.dalpha = dalpha;
     p.nb = nb; p.npix = (int)npix; p.c = c; p.eps = 1e-5f;
     fill_drop(p, dropout, seed, layer);
-    MI_HIP(hipMemsetAsync(bstats, 0, (size_t)nb * MI_NSLOT * c * 2 * sizeof(float), (hipStream_t)stream));
+    MI_HIP(hipMemsetAsync(bstats, 0, (size_t)nb * MI_NSLOT * c * 2 * sizeof(double), (hipStream_t)stream));
     return launch_norm_bwd(dtype, p, (hipStream_t)stream);
 }
 

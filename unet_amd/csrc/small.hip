@@ -11,7 +11,7 @@ namespace {
 template <class TR>
 __global__ __launch_bounds__(256) void c1_s2_fwd_kernel(const C1Params p) {
     constexpr int ESZ = TR::ESZ;
-    extern __shared__ __attribute__((aligned(16))) float sm[];  // weights [N][KK], then stats [N][2]
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // weights [N][KK], then partials [2][ppb][N]
     const int KZ = p.ndim == 3 ? 3 : 1;
     const int KK = KZ * 9;
     const int G = p.N / 8;
@@ -22,7 +22,6 @@ __global__ __launch_bounds__(256) void c1_s2_fwd_kernel(const C1Params p) {
         const int n = i / KK, k = i - n * KK;
         wl[i] = (n < p.n_w1) ? p.w[n * KK + k] : p.w2[(n - p.n_w1) * KK + k];
     }
-    for (int i = threadIdx.x; i < p.N * 2; i += 256) sst[i] = 0.f;
     __syncthreads();
     const int cpix = p.cd[0] * p.cd[1] * p.cd[2];
     const int grp = threadIdx.x % G, pl = threadIdx.x / G;
@@ -53,13 +52,6 @@ __global__ __launch_bounds__(256) void c1_s2_fwd_kernel(const C1Params p) {
                 }
             }
         }
-        if (p.stats) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int ch = grp * 8 + e;
-                if (ch < p.nstat) { atomicAdd(&sst[ch * 2], acc[e]); atomicAdd(&sst[ch * 2 + 1], acc[e] * acc[e]); }
-            }
-        }
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -70,10 +62,23 @@ __global__ __launch_bounds__(256) void c1_s2_fwd_kernel(const C1Params p) {
         store_n<TR, 8>(p.y_out + (gp * p.y_pitch + p.y_coff + grp * 8) * ESZ, o);
     }
     if (p.stats) {
+        // fixed-order reduction over the workgroup's pixels, then fp64 accumulators
+        if (pl < ppb) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = valid ? acc[e] : 0.f;
+                sst[pl * p.N + grp * 8 + e] = v;
+                sst[(ppb + pl) * p.N + grp * 8 + e] = v * v;
+            }
+        }
         __syncthreads();
         const int slot = blockIdx.x % MI_NSLOT;
-        for (int i = threadIdx.x; i < p.nstat * 2; i += 256)
-            atomicAdd(&p.stats[(((size_t)img * MI_NSLOT + slot) * p.stats_c) * 2 + i], sst[i]);
+        for (int i = threadIdx.x; i < p.nstat * 2; i += 256) {
+            const int ch = i >> 1, k = i & 1;
+            float a = 0.f;
+            for (int r = 0; r < ppb; ++r) a += sst[(k * ppb + r) * p.N + ch];
+            atomicAdd(&p.stats[(((size_t)img * MI_NSLOT + slot) * p.stats_c) * 2 + i], (double)a);
+        }
     }
 }
 
@@ -139,8 +144,8 @@ __global__ __launch_bounds__(256) void c1_s2_T_kernel(const C1Params p) {
         __syncthreads();
         if (threadIdx.x == 0) {
             const int slot = blockIdx.x % MI_NSLOT;
-            atomicAdd(&p.stats[((size_t)img * MI_NSLOT + slot) * 2], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-            atomicAdd(&p.stats[((size_t)img * MI_NSLOT + slot) * 2 + 1], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+            atomicAdd(&p.stats[((size_t)img * MI_NSLOT + slot) * 2], (double)(((red[0][0] + red[0][1]) + red[0][2]) + red[0][3]));
+            atomicAdd(&p.stats[((size_t)img * MI_NSLOT + slot) * 2 + 1], (double)(((red[1][0] + red[1][1]) + red[1][2]) + red[1][3]));
         }
     }
 }
@@ -150,12 +155,12 @@ __global__ __launch_bounds__(256) void c1_s2_T_kernel(const C1Params p) {
 template <class TR>
 __global__ __launch_bounds__(256) void c1_s2_wgrad_kernel(const C1Params p) {
     constexpr int ESZ = TR::ESZ;
-    extern __shared__ __attribute__((aligned(16))) float sm[];  // [N][10]
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // [4 waves][N][10]
     const int KZ = p.ndim == 3 ? 3 : 1;
     const int KK = KZ * 9;
     const int kz = blockIdx.y;
     const int G = p.N / 8;
-    for (int i = threadIdx.x; i < p.N * 10; i += 256) sm[i] = 0.f;
+    for (int i = threadIdx.x; i < 4 * p.N * 10; i += 256) sm[i] = 0.f;
     __syncthreads();
     const int cpix = p.cd[0] * p.cd[1] * p.cd[2];
     const int fpix = p.fd[0] * p.fd[1] * p.fd[2];
@@ -210,22 +215,39 @@ __global__ __launch_bounds__(256) void c1_s2_wgrad_kernel(const C1Params p) {
             accb[e] = b;
         }
     }
-    if (pow2 ? ((threadIdx.x & 63) < G) : (pl < ppb)) {
+    // one LDS image per wave; when the channel groups tile the wave each entry has a single writer and the
+    // result is order-independent, otherwise (N/8 not a power of two) LDS float atomics are used
+    float* mine = sm + (threadIdx.x >> 6) * p.N * 10;
+    if (pow2) {
+        if ((threadIdx.x & 63) < G) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) mine[(grp * 8 + e) * 10 + k] = acc[e][k];
+                mine[(grp * 8 + e) * 10 + 9] = accb[e];
+            }
+        }
+    } else if (pl < ppb) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
 #pragma unroll
-            for (int k = 0; k < 9; ++k) atomicAdd(&sm[(grp * 8 + e) * 10 + k], acc[e][k]);
-            atomicAdd(&sm[(grp * 8 + e) * 10 + 9], accb[e]);
+            for (int k = 0; k < 9; ++k) atomicAdd(&mine[(grp * 8 + e) * 10 + k], acc[e][k]);
+            atomicAdd(&mine[(grp * 8 + e) * 10 + 9], accb[e]);
         }
     }
     __syncthreads();
     const size_t slab = blockIdx.x;
+    const int wstride = p.N * 10;
     for (int i = threadIdx.x; i < p.N * 9; i += 256) {
         const int n = i / 9, k = i - n * 9;
-        p.partial[(slab * KK + kz * 9 + k) * p.N + n] = sm[n * 10 + k];
+        const int o = n * 10 + k;
+        p.partial[(slab * KK + kz * 9 + k) * p.N + n] = ((sm[o] + sm[wstride + o]) + sm[2 * wstride + o]) + sm[3 * wstride + o];
     }
     if (kz == 0)
-        for (int n = threadIdx.x; n < p.N; n += 256) p.partial_bias[slab * p.N + n] = sm[n * 10 + 9];
+        for (int n = threadIdx.x; n < p.N; n += 256) {
+            const int o = n * 10 + 9;
+            p.partial_bias[slab * p.N + n] = ((sm[o] + sm[wstride + o]) + sm[2 * wstride + o]) + sm[3 * wstride + o];
+        }
 }
 
 // ---- one-channel 3^d stencil: out = sum_k w[k] * in[p + k - 1] + bias + addend ------------
@@ -319,7 +341,7 @@ int launch_c1_s2_fwd(int dtype, const C1Params& p, hipStream_t st) {
     const int KK = p.ndim == 3 ? 27 : 9;
     const int cpix = p.cd[0] * p.cd[1] * p.cd[2];
     const int ppb = 256 / (p.N / 8);
-    const size_t lds = (size_t)(p.N * KK + p.N * 2) * sizeof(float);
+    const size_t lds = (size_t)(p.N * KK + 2 * ppb * p.N) * sizeof(float);
     dim3 grid((cpix + ppb - 1) / ppb, p.nb);
     if (dtype) hipLaunchKernelGGL(c1_s2_fwd_kernel<BF16>, grid, dim3(256), lds, st, p);
     else hipLaunchKernelGGL(c1_s2_fwd_kernel<F32>, grid, dim3(256), lds, st, p);
@@ -340,7 +362,7 @@ int launch_c1_s2_T(int dtype, const C1Params& p, hipStream_t st) {
 // partial: [nsplit][KK][N] floats, partial_bias: [nsplit][N] floats
 int launch_c1_s2_wgrad(int dtype, const C1Params& p, hipStream_t st) {
     MI_CHECK(p.N % 8 == 0 && p.N >= 8 && p.N <= 512, "N must be a multiple of 8, at most 512");
-    const size_t lds = (size_t)p.N * 10 * sizeof(float);
+    const size_t lds = (size_t)4 * p.N * 10 * sizeof(float);
     dim3 grid(p.nsplit, p.ndim == 3 ? 3 : 1);
     if (dtype) hipLaunchKernelGGL(c1_s2_wgrad_kernel<BF16>, grid, dim3(256), lds, st, p);
     else hipLaunchKernelGGL(c1_s2_wgrad_kernel<F32>, grid, dim3(256), lds, st, p);

@@ -17,7 +17,7 @@ class _DiceCEFunction(torch.autograd.Function):
         nb = logits.shape[0]
         npix = logits[0].numel()
         dev = logits.device
-        sums = torch.empty(nb * 4, dtype=torch.float32, device=dev)
+        sums = torch.empty(nb * 4, dtype=torch.float64, device=dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         st = _lib.current_stream(dev)
         _lib.check(lib.mi_dice_ce_loss_fwd(logits.data_ptr(), target.data_ptr(), _lib.label_dtype_code(target),

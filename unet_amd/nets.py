@@ -179,8 +179,8 @@ class _Plan:
                                             1 if training else 0, C.c_uint64(seed), _lib.current_stream(x.device)),
                    "mi_unet_forward")
 
-    def backward(self, flat, dlogits, flat_grad, ws, training, seed, bucket=-1):
-        _lib.check(self.lib.mi_unet_backward(self.h, flat.data_ptr(), dlogits.data_ptr(), flat_grad.data_ptr(),
+    def backward(self, flat, x, dlogits, flat_grad, ws, training, seed, bucket=-1):
+        _lib.check(self.lib.mi_unet_backward(self.h, flat.data_ptr(), x.data_ptr(), dlogits.data_ptr(), flat_grad.data_ptr(),
                                              ws.data_ptr(), 1 if training else 0, C.c_uint64(seed), bucket,
                                              _lib.current_stream(dlogits.device)),
                    "mi_unet_backward")
@@ -201,8 +201,7 @@ class _WorkspaceLease:
 
 class _UNetFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, x, *params):
-        need_bwd = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+    def forward(ctx, model, need_bwd, x, *params):
         plan = model._plan_for(x, need_bwd)
         flat = model._flat
         logits = torch.empty_like(x)
@@ -213,6 +212,7 @@ class _UNetFunction(torch.autograd.Function):
             ctx.plan, ctx.seed, ctx.model = plan, seed, weakref.ref(model)
             ctx.lease = _WorkspaceLease(plan, ws)
             ctx.training = model.training
+            ctx.x = x
         else:
             plan.give_workspace(ws)
         return logits
@@ -227,11 +227,12 @@ class _UNetFunction(torch.autograd.Function):
         if dlogits.dtype != torch.float32:
             dlogits = dlogits.float()
         g = torch.empty_like(model._flat)
-        plan.backward(model._flat, dlogits, g, ctx.lease.ws, ctx.training, ctx.seed)
+        plan.backward(model._flat, ctx.x, dlogits, g, ctx.lease.ws, ctx.training, ctx.seed)
         model._last_grad_flat = g
         grads = tuple(g[o:o + n].view(s) for (_, s, n, o, _) in model._ptable_ordered)
         ctx.lease = None
-        return (None, None) + grads
+        ctx.x = None
+        return (None, None, None) + grads
 
 
 class UNet(nn.Module):
@@ -408,5 +409,7 @@ class UNet(nn.Module):
         if xin.dtype != torch.float32:
             xin = xin.float()
         self._ensure_flat(xin.device)
-        out = _UNetFunction.apply(self, xin, *self.parameters())
+        params = list(self.parameters())
+        need_bwd = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        out = _UNetFunction.apply(self, need_bwd, xin, *params)
         return out if in_dtype == torch.float32 else out.to(in_dtype)

@@ -55,14 +55,14 @@ def pack_weights(w: torch.Tensor, x_shape, ksize, stride, transposed, dtype, dgr
 
 
 def conv_forward(x, w, bias=None, ksize=3, stride=1, transposed=False, addend=None, want_stats=False):
-    """x: channels-last; w: torch layout fp32.  Returns y (channels-last) [, stats [N,8,Cout,2]]."""
+    """x: channels-last; w: torch layout fp32.  Returns y (channels-last) [, stats [N,8,Cout,2] fp64]."""
     lib = _lib.load()
     cin, cout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
     d = _desc(x.shape, cin, cout, ksize, stride, transposed, x.dtype)
     packed = pack_weights(w, x.shape, ksize, stride, transposed, x.dtype, False)
     osp = _out_spatial(list(x.shape[1:-1]), ksize, stride, transposed)
     y = torch.empty([x.shape[0]] + osp + [cout], dtype=x.dtype, device=x.device)
-    stats = torch.zeros(x.shape[0], 8, cout, 2, dtype=torch.float32, device=x.device) if want_stats else None
+    stats = torch.zeros(x.shape[0], 8, cout, 2, dtype=torch.float64, device=x.device) if want_stats else None
     b = bias.contiguous().float() if bias is not None else None
     tx, ty, ta = _ten(x), _ten(y), _ten(addend)
     _lib.check(lib.mi_conv_forward(C.byref(d), C.byref(tx), packed.data_ptr(), _lib.ptr(b), C.byref(ty),
@@ -117,7 +117,7 @@ def instnorm_prelu_bwd(dy, raw, stats, alpha, dropout=0.0, seed=0, layer=0):
     nb, c = raw.shape[0], raw.shape[-1]
     npix = raw[0].numel() // c
     dx = torch.empty_like(raw)
-    bstats = torch.empty(nb * 8 * c * 2, dtype=torch.float32, device=raw.device)
+    bstats = torch.empty(nb * 8 * c * 2, dtype=torch.float64, device=raw.device)
     dalpha = torch.zeros(1, dtype=torch.float32, device=raw.device)
     tdy, traw, tdx = _ten(dy), _ten(raw), _ten(dx)
     _lib.check(lib.mi_instnorm_prelu_bwd(_DT[raw.dtype], nb, npix, c, C.byref(tdy), C.byref(traw), stats.data_ptr(),

@@ -40,7 +40,7 @@ class Trainer:
             dev = x.device
             plan = self.model._plan_for(x, True)
             b = dict(plan=plan, logits=torch.empty_like(x), dlogits=torch.empty_like(x),
-                     sums=torch.empty(x.shape[0] * 4, dtype=torch.float32, device=dev),
+                     sums=torch.empty(x.shape[0] * 4, dtype=torch.float64, device=dev),
                      loss=torch.zeros(1, dtype=torch.float32, device=dev),
                      ws=torch.empty(plan.workspace_bytes, dtype=torch.uint8, device=dev))
             self._bufs[key] = b
@@ -97,11 +97,11 @@ class Trainer:
                    "mi_dice_ce_loss_bwd")
         if self._reducer is not None and self.overlap:
             for bucket in range(3):
-                plan.backward(flat, b["dlogits"], self._grad, b["ws"], True, seed, bucket)
+                plan.backward(flat, x, b["dlogits"], self._grad, b["ws"], True, seed, bucket)
                 self._reducer.launch(bucket)
             self._reducer.wait()
         else:
-            plan.backward(flat, b["dlogits"], self._grad, b["ws"], True, seed, -1)
+            plan.backward(flat, x, b["dlogits"], self._grad, b["ws"], True, seed, -1)
             if self._reducer is not None:
                 for bucket in range(3):
                     self._reducer.launch(bucket)
