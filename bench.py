@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""Benchmark of the U-Net training hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the reference's inner training loop body (reference/train.py:111-119) over one
+synthetic batch: forward, Dice loss, backward, (gradient all-reduce when N > 1) and AdamW, as HIP
+kernels on one stream.  Workload at N = 1: BASELINE.json configs[1] - 2-D residual U-Net
+(channels 16-256, 2 res units), bf16 activations, 32 slices of 512x512 per GPU.  For N > 1 the script is
+launched by torch.distributed.run (one rank per GPU, RCCL), every rank keeps 32 slices (weak scaling).
+
+Rank 0 prints ONE JSON line on stdout; per-kernel tables go to stderr.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK = 2.5e15   # dense bf16 MFMA, FLOP/s (MI355X)
+HBM_PEAK = 8.0e12         # HBM3E, B/s
+RIDGE = MFMA_BF16_PEAK / HBM_PEAK
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def synthetic_batch(nb, sp, seed, device):
+    """Images ~ U[0,1) (the reference scales CT intensities to [0,1]); labels = one disk per slice with
+    5-25 % foreground and an inner disk of value 2 (exercises the label fold of train.py:112-113)."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(nb, 1, *sp, generator=g)
+    grids = torch.meshgrid(*[torch.arange(s, dtype=torch.float32) for s in sp], indexing="ij")
+    t = torch.zeros(nb, 1, *sp)
+    for b in range(nb):
+        c = [(0.3 + 0.4 * torch.rand(1, generator=g).item()) * s for s in sp]
+        r = (0.1 + 0.2 * torch.rand(1, generator=g).item()) * min(sp)
+        d2 = sum((gr - ci) ** 2 for gr, ci in zip(grids, c))
+        t[b, 0] = (d2 < r * r).float()
+        t[b, 0][d2 < (0.4 * r) ** 2] = 2.0
+    return x.to(device), t.to(device)
+
+
+def cpu_baseline(budget_s=15.0):
+    """The CPU oracle (plain torch restatement of the reference path) on BASELINE.json configs[0]:
+    2-D 16-256 U-Net, fp32, batch 8 of 256x256, forward + DiceCE loss + backward + AdamW."""
+    import oracle
+
+    threads = torch.get_num_threads()
+    torch.manual_seed(0)
+    model = oracle.UNet(2, 1, 1, (16, 32, 64, 128, 256), (2, 2, 2, 2), num_res_units=2, dropout=0.0)
+    loss = oracle.DiceCELoss(to_onehot_y=False, sigmoid=True)
+    opt = torch.optim.AdamW(model.parameters(), lr=5e-4)
+    x, t = synthetic_batch(8, (256, 256), 1234, "cpu")
+    t[t == 2] = 1
+
+    def step():
+        opt.zero_grad()
+        loss(model(x), t).backward()
+        opt.step()
+
+    step()  # warm-up (thread pool, allocator)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 400:
+            break
+    return {"value": round(8 * n / el, 2), "unit": "slices/s", "cores": threads, "kind": "port",
+            "sample": f"{n} steps of batch 8 x 256x256 fp32 (fwd+loss+bwd+AdamW) in {el:.1f} s; "
+                      f"configs[0]; oracle = torch-CPU restatement of the reference path"}
+
+
+def kernel_table(plan, nsteps):
+    rows = {}
+    for backward in (False, True):
+        for s in plan.steps(backward):
+            if s["launches"] == 0:
+                continue
+            r = rows.setdefault(s["kernel"], dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
+            r["ms"] += s["total_ms"]
+            r["launches"] += s["launches"]
+            r["bytes"] += s["bytes"] * s["launches"]
+            if s["work_is_flops"]:
+                r["flops"] += s["work"] * s["launches"]
+    return rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=32, help="slices per GPU")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--dims", type=int, default=2, choices=(2, 3))
+    ap.add_argument("--dtype", default="bf16", choices=("bf16", "fp32"))
+    ap.add_argument("--dropout", type=float, default=0.0)
+    ap.add_argument("--channels", default="16,32,64,128,256")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="all-reduce after the whole backward")
+    args = ap.parse_args()
+
+    import unet_amd
+    from unet_amd.parallel import init_from_env, broadcast_parameters
+    import torch.distributed as dist
+
+    rank, world, local = init_from_env()
+    if world != args.gpus:
+        log(f"[bench] note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an AMD GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    channels = tuple(int(c) for c in args.channels.split(","))
+    sp = (args.size,) * args.dims
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.manual_seed(0)
+    model = unet_amd.UNet(args.dims, 1, 1, channels, (2,) * (len(channels) - 1), num_res_units=2, dropout=args.dropout,
+                          compute_dtype=dtype).to(dev).train()
+    broadcast_parameters(model.flat_parameters())
+    loss = unet_amd.DiceLoss(sigmoid=True, fold_label_two=True)
+    opt = unet_amd.AdamW(model.parameters(), lr=5e-4, weight_decay=1e-5, model=model)
+    trainer = unet_amd.Trainer(model, loss, opt, overlap=not args.no_overlap)
+    x, t = synthetic_batch(args.batch, sp, 1234 + rank, dev)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(x, t)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.step(x, t)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    last_loss = trainer.loss_sum() / max(1, args.steps + args.warmup)
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * args.batch * args.steps / elapsed
+
+    plan = model._plan_for(x, True)
+    flops_step = plan.flops(False) + plan.flops(True)
+    out = {
+        "metric": "train slices/sec (whole node) 2D U-Net 512x512 bf16" if args.dims == 2 else "train patches/sec (whole node) 3D U-Net",
+        "value": round(value, 2), "unit": "slices/s" if args.dims == 2 else "patches/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"{args.dims}D residual U-Net ch {'-'.join(map(str, channels))}, 2 res units, "
+                               f"{'x'.join(map(str, sp))} 1-ch {'slices' if args.dims == 2 else 'patches'}, "
+                               f"batch {args.batch}/GPU, Dice loss, AdamW (BASELINE.json configs[1])",
+                   "global_batch": world * args.batch, "parallelism": f"dp{world}", "dropout": args.dropout,
+                   "conv_gflop_per_step_per_gpu": round(flops_step / 1e9, 1)},
+        "mean_loss": round(last_loss, 5),
+    }
+
+    if rank == 0 and world == 1 and not args.no_kernel_timing:
+        # per-kernel durations: the same step repeated with every launch bracketed by HIP events on its stream
+        lib = plan.lib
+        lib.mi_unet_prof_reset(plan.h)
+        lib.mi_unet_prof_enable(plan.h, 1)
+        nprof = min(args.steps, 10)
+        for _ in range(nprof):
+            trainer.step(x, t)
+        torch.cuda.synchronize()
+        lib.mi_unet_prof_collect(plan.h)
+        lib.mi_unet_prof_enable(plan.h, 0)
+        rows = kernel_table(plan, nprof)
+        tot_ms = sum(r["ms"] for r in rows.values())
+        log(f"[bench] per-kernel time over {nprof} instrumented steps ({tot_ms / nprof:.3f} ms/step in kernels):")
+        log(f"  {'kernel':44s} {'ms/step':>9s} {'launch/step':>11s} {'avg us':>9s} {'TFLOP/s':>9s} {'GB/s':>9s}")
+        for k, r in sorted(rows.items(), key=lambda kv: -kv[1]["ms"]):
+            sec = r["ms"] / 1e3
+            log(f"  {k:44s} {r['ms'] / nprof:9.4f} {r['launches'] / nprof:11.1f} {1e3 * r['ms'] / max(1, r['launches']):9.2f} "
+                f"{(r['flops'] / sec / 1e12 if sec else 0):9.1f} {(r['bytes'] / sec / 1e9 if sec else 0):9.1f}")
+        if os.environ.get("BENCH_LAYERS"):
+            log("[bench] per-launch (layer) averages:")
+            for backward in (False, True):
+                for s in plan.steps(backward):
+                    if s["launches"]:
+                        us = 1e3 * s["total_ms"] / s["launches"]
+                        tf = s["work"] / (us * 1e-6) / 1e12 if s["work_is_flops"] else 0.0
+                        log(f"  {'bwd' if backward else 'fwd'} {s['layer']:48s} {s['kernel']:34s} {us:9.2f} us {tf:8.1f} TF/s {s['bytes'] / (us * 1e-6) / 1e9:9.1f} GB/s")
+        conv = {k: r for k, r in rows.items() if r["flops"] > 0 and ("igemm" in k or "wgrad_kernel" in k)}
+        conv_s = sum(r["ms"] for r in conv.values()) / 1e3
+        conv_f = sum(r["flops"] for r in conv.values())
+        out["mfma_util"] = round(conv_f / conv_s / MFMA_BF16_PEAK, 4) if conv_s else None
+        dom_name, dom = max(rows.items(), key=lambda kv: kv[1]["ms"])
+        sec = dom["ms"] / 1e3
+        ai = dom["flops"] / max(dom["bytes"], 1.0)
+        if dom["flops"] > 0 and ai > RIDGE and args.dtype == "bf16":
+            roof = {"bound": "mfma", "achieved": round(dom["flops"] / sec / 1e12, 2), "peak": MFMA_BF16_PEAK / 1e12,
+                    "unit": "TFLOP/s"}
+        else:
+            roof = {"bound": "hbm", "achieved": round(dom["bytes"] / sec / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s"}
+        roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
+        roof["traffic"] = None
+        roof["kernel"] = dom_name
+        roof["avg_launch_us"] = round(1e3 * dom["ms"] / dom["launches"], 2)
+        roof["launches_per_step"] = round(dom["launches"] / nprof, 1)
+        roof["share_of_kernel_time"] = round(dom["ms"] / tot_ms, 3)
+        out["roofline"] = roof
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

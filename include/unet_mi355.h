@@ -90,6 +90,7 @@ typedef struct mi_step_info {
     char kernel[96];           /* kernel (template instance) it runs */
     double work;               /* algorithmic flops (convolutions) or bytes (everything else) per launch */
     int32_t work_is_flops;
+    double bytes;              /* algorithmic HBM bytes per launch (tensors read once + written once) */
     double total_ms;           /* accumulated by mi_unet_prof_collect */
     int64_t launches;
 } mi_step_info;

@@ -33,7 +33,7 @@ class MiParamInfo(C.Structure):
 class MiStepInfo(C.Structure):
     _fields_ = [
         ("layer", C.c_char * 96), ("kernel", C.c_char * 96), ("work", C.c_double), ("work_is_flops", C.c_int32),
-        ("total_ms", C.c_double), ("launches", C.c_int64),
+        ("bytes", C.c_double), ("total_ms", C.c_double), ("launches", C.c_int64),
     ]
 
 

@@ -48,7 +48,7 @@ struct TabArgs { int first, count, max_elems; };
 
 struct Step {
     int kind = 0, dtype = 0, bucket = 0;
-    double work = 0; int work_is_flops = 0;
+    double work = 0; int work_is_flops = 0; double bytes = 0;
     std::string layer, kernel;
     IgemmParams ig; WgradParams wg; NormParams nm; C1Params c1; StencilParams stn;
     AddArgs add; MemsetArgs ms; TabArgs tab;
@@ -218,6 +218,10 @@ struct Builder {
         s.kernel = kb;
         double bpix = (double)p.bd[0] * p.bd[1] * p.bd[2] * u.nb;
         s.work = 2.0 * bpix * (double)(*ntaps_out) * K * N; s.work_is_flops = 1;
+        {
+            const double ipix = (double)p.id[0] * p.id[1] * p.id[2] * u.nb, opix = (double)p.od[0] * p.od[1] * p.od[2] * u.nb;
+            s.bytes = (ipix * K + opix * N * (addend ? 2.0 : 1.0)) * u.esz + (double)(*ntaps_out) * K * N * u.esz;
+        }
         if (&list == &u.fwd) u.flops_fwd += s.work; else u.flops_bwd += s.work;
         return true;
     }
@@ -251,6 +255,7 @@ struct Builder {
         s.kernel = kb;
         double bpix = (double)p.bd[0] * p.bd[1] * p.bd[2] * u.nb;
         s.work = 2.0 * bpix * p.ntaps_total * (double)F * S; s.work_is_flops = 1;
+        s.bytes = (bpix * F + (double)p.sd[0] * p.sd[1] * p.sd[2] * u.nb * S) * u.esz + (double)p.ntaps_total * F * S * 4.0;
         u.flops_bwd += s.work;
     }
 
@@ -1107,6 +1112,7 @@ int mi_unet_step_info(const mi_unet* u, int backward, int i, mi_step_info* info)
     snprintf(info->layer, sizeof(info->layer), "%s", s.layer.c_str());
     snprintf(info->kernel, sizeof(info->kernel), "%s", s.kernel.c_str());
     info->work = s.work; info->work_is_flops = s.work_is_flops; info->total_ms = s.total_ms; info->launches = s.launches;
+    info->bytes = s.work_is_flops ? s.bytes : s.work;
     return 0;
 }
 

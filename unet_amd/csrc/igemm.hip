@@ -404,28 +404,74 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
             }
         }
     }
-    // ---- write this wave's slab ---------------------------------------------------
-    const size_t slab = (size_t)blockIdx.x * WK + wk;
+    // ---- combine the WK pixel-split waves in a fixed order through LDS, then write one slab -------
+    if (WK > 1) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);   // [WK][(NT*FF*SF + FF)*4][64 lanes]
+        constexpr int NV = (NT * FF * SF + FF) * 4;
+        const int sub = wave % (WF * WS);              // waves that share (wf, ws) hold the same output fragment set
+        float* mine = red + ((size_t)(wk * WF * WS + sub) * NV) * 64 + lane;
+        int v = 0;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const size_t tbase = (slab * p.ntaps_total + (size_t)tgi * NT + t) * p.F;
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int a = 0; a < FF; ++a)
+#pragma unroll
+                for (int b = 0; b < SF; ++b)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mine[(v++) * 64] = acc[t][a][b][j];
 #pragma unroll
         for (int a = 0; a < FF; ++a)
 #pragma unroll
-            for (int b = 0; b < SF; ++b)
+            for (int j = 0; j < 4; ++j) mine[(v++) * 64] = accb[a][j];
+        __syncthreads();
+        if (wk == 0) {
+            v = 0;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int a = 0; a < FF; ++a)
+#pragma unroll
+                    for (int b = 0; b < SF; ++b)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float r = acc[t][a][b][j];
+                            for (int k = 1; k < WK; ++k) r += red[((size_t)(k * WF * WS + sub) * NV + v) * 64 + lane];
+                            acc[t][a][b][j] = r; ++v;
+                        }
+#pragma unroll
+            for (int a = 0; a < FF; ++a)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int f = fb0 + (wf * FF + a) * 16 + 4 * g + j;
-                    const int s = sb0 + (ws * SF + b) * 16 + lr;
-                    p.partial[(tbase + f) * p.S + s] = acc[t][a][b][j];
+                    float r = accb[a][j];
+                    for (int k = 1; k < WK; ++k) r += red[((size_t)(k * WF * WS + sub) * NV + v) * 64 + lane];
+                    accb[a][j] = r; ++v;
                 }
+        }
     }
-    if (do_bias && lr == 0) {
+    if (wk == 0) {
+        const size_t slab = (size_t)blockIdx.x;
 #pragma unroll
-        for (int a = 0; a < FF; ++a)
+        for (int t = 0; t < NT; ++t) {
+            const size_t tbase = (slab * p.ntaps_total + (size_t)tgi * NT + t) * p.F;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                p.partial_bias[slab * p.F + fb0 + (wf * FF + a) * 16 + 4 * g + j] = accb[a][j];
+            for (int a = 0; a < FF; ++a)
+#pragma unroll
+                for (int b = 0; b < SF; ++b)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int f = fb0 + (wf * FF + a) * 16 + 4 * g + j;
+                        const int s = sb0 + (ws * SF + b) * 16 + lr;
+                        p.partial[(tbase + f) * p.S + s] = acc[t][a][b][j];
+                    }
+        }
+        if (do_bias && lr == 0) {
+#pragma unroll
+            for (int a = 0; a < FF; ++a)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    p.partial_bias[slab * p.F + fb0 + (wf * FF + a) * 16 + 4 * g + j] = accb[a][j];
+        }
     }
 }
 
@@ -445,24 +491,43 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackDesc* __restrict__ 
     pack_body<TR>(d);
 }
 
+// 256 threads = 64 output elements x 4 slab groups; each thread sums its slabs in order, the four group
+// sums are combined in a fixed order through LDS (bitwise reproducible).
 __device__ __forceinline__ void reduce_body(const ReduceDesc& d) {
+    __shared__ float part[4][64];
     const int nw = d.ntaps * d.Fcnt * d.S;
     const int total = nw + (d.dst_b ? d.Fcnt : 0);
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    const size_t stride = (size_t)d.ntaps * d.Ftot * d.S;
+    for (int base = blockIdx.x * 64; base < total; base += gridDim.x * 64) {
+        const int i = base + lx;
+        float a = 0.f;
+        int s = 0, f = 0, t = 0;
         if (i < nw) {
-            const int s = i % d.S; const int r = i / d.S;
-            const int f = r % d.Fcnt; const int t = r / d.Fcnt;
-            float a = 0.f;
-            const size_t stride = (size_t)d.ntaps * d.Ftot * d.S;
+            s = i % d.S; const int r = i / d.S;
+            f = r % d.Fcnt; t = r / d.Fcnt;
             const size_t off = ((size_t)t * d.Ftot + d.f_off + f) * d.S + s;
-            for (int sl = 0; sl < d.nslab; ++sl) a += d.partial[sl * stride + off];
-            d.dst_w[((size_t)f * d.S + s) * d.KK + d.kidx[t]] = a;
-        } else {
-            const int f = i - nw;
-            float a = 0.f;
-            for (int sl = 0; sl < d.nslab; ++sl) a += d.partial_bias[(size_t)sl * d.Ftot + d.f_off + f];
-            d.dst_b[f] = a;
+            int sl = ly;
+            for (; sl + 28 < d.nslab; sl += 32) {   // eight independent loads in flight, summed in slab order
+                const float v0 = d.partial[(size_t)sl * stride + off], v1 = d.partial[(size_t)(sl + 4) * stride + off];
+                const float v2 = d.partial[(size_t)(sl + 8) * stride + off], v3 = d.partial[(size_t)(sl + 12) * stride + off];
+                const float v4 = d.partial[(size_t)(sl + 16) * stride + off], v5 = d.partial[(size_t)(sl + 20) * stride + off];
+                const float v6 = d.partial[(size_t)(sl + 24) * stride + off], v7 = d.partial[(size_t)(sl + 28) * stride + off];
+                a = (((((((a + v0) + v1) + v2) + v3) + v4) + v5) + v6) + v7;
+            }
+            for (; sl < d.nslab; sl += 4) a += d.partial[(size_t)sl * stride + off];
+        } else if (i < total) {
+            f = i - nw;
+            for (int sl = ly; sl < d.nslab; sl += 4) a += d.partial_bias[(size_t)sl * d.Ftot + d.f_off + f];
         }
+        part[ly][lx] = a;
+        __syncthreads();
+        if (ly == 0 && i < total) {
+            const float v = ((part[0][lx] + part[1][lx]) + part[2][lx]) + part[3][lx];
+            if (i < nw) d.dst_w[((size_t)f * d.S + s) * d.KK + d.kidx[t]] = v;
+            else d.dst_b[f] = v;
+        }
+        __syncthreads();
     }
 }
 __global__ __launch_bounds__(256) void reduce_one_kernel(const ReduceDesc d) { reduce_body(d); }
@@ -516,6 +581,11 @@ int launch_wgrad_t(const WgradParams& p, hipStream_t st) {
     constexpr int FPITCH = FB * TR::ESZ + 16, SPITCH = SB * TR::ESZ + 16;
     const int PP = p.pd[0] * p.pd[1] * p.pd[2];
     size_t lds = (size_t)256 * FPITCH + (size_t)PP * SPITCH;
+    constexpr int WK = 4 / (WF * WS);
+    if (WK > 1) {
+        const size_t comb = (size_t)4 * (NT * FF * SF + FF) * 4 * 64 * sizeof(float);
+        if (comb > lds) lds = comb;
+    }
     auto kern = wgrad_kernel<TR, NT, FF, SF, WF, WS>;
     if (int r = set_lds(kern, lds)) return r;
     dim3 grid(p.nsplit, p.F / FB, (p.S / SB) * p.ntapg);
@@ -599,9 +669,8 @@ void wgrad_config(int dtype, const WgradParams& p, int* ff, int* sf, int* wf, in
 }
 
 int wgrad_slabs(int dtype, const WgradParams& p) {
-    int ff, sf, wf, wsn;
-    wgrad_config(dtype, p, &ff, &sf, &wf, &wsn);
-    return p.nsplit * (4 / (wf * wsn));
+    (void)dtype;
+    return p.nsplit;   // the pixel-split waves of a workgroup are combined before the slab is written
 }
 
 size_t wgrad_lds_bytes(int dtype, const WgradParams& p) {
@@ -635,8 +704,8 @@ int launch_wgrad(int dtype, const WgradParams& p, hipStream_t st) {
 
 int launch_reduce(const ReduceDesc* d_descs, int ndesc, int max_elems, hipStream_t st) {
     if (ndesc <= 0) return 0;
-    int gx = (max_elems + 255) / 256;
-    if (gx > 64) gx = 64;
+    int gx = (max_elems + 63) / 64;
+    if (gx > 2048) gx = 2048;
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL(reduce_kernel, dim3(gx, ndesc), dim3(256), 0, st, d_descs);
     hipError_t e = hipGetLastError();
@@ -658,7 +727,7 @@ int launch_pack(int dtype, const PackDesc* d_descs, int ndesc, int max_elems, hi
 
 int launch_reduce_one(const ReduceDesc& d, hipStream_t st) {
     int total = d.ntaps * d.Fcnt * d.S + d.Fcnt;
-    int gx = (total + 255) / 256; if (gx > 64) gx = 64; if (gx < 1) gx = 1;
+    int gx = (total + 63) / 64; if (gx > 2048) gx = 2048; if (gx < 1) gx = 1;
     hipLaunchKernelGGL(reduce_one_kernel, dim3(gx), dim3(256), 0, st, d);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { mi_set_error(std::string("reduce launch: ") + hipGetErrorString(e)); return -2; }

@@ -289,7 +289,15 @@ int check_launch(const char* what) {
 }  // namespace
 
 int norm_bwd_reduce_blocks(int npix, int c) {
-    int g = (npix + 2047) / 2048;
+    // about 16 pixel sweeps per thread: a sweep covers 256 / (16-byte vectors per pixel) pixels
+    int per_block = 2048;
+    if (c > 1) {
+        int vec_pp = c / 4; if (vec_pp > 256) vec_pp = 256; if (vec_pp < 1) vec_pp = 1;   // >= vectors per pixel in either dtype
+        per_block = (256 / vec_pp) * 16 * 2;
+        if (per_block < 64) per_block = 64;
+        if (per_block > 2048) per_block = 2048;
+    }
+    int g = (npix + per_block - 1) / per_block;
     const int cap = c == 1 ? 128 : 256;
     if (g < 1) g = 1;
     if (g > cap) g = cap;

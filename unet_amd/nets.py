@@ -161,7 +161,8 @@ class _Plan:
             info = _lib.MiStepInfo()
             _lib.check(self.lib.mi_unet_step_info(self.h, 1 if backward else 0, i, C.byref(info)))
             out.append(dict(layer=info.layer.decode(), kernel=info.kernel.decode(), work=info.work,
-                            work_is_flops=bool(info.work_is_flops), total_ms=info.total_ms, launches=info.launches))
+                            work_is_flops=bool(info.work_is_flops), bytes=info.bytes, total_ms=info.total_ms,
+                            launches=info.launches))
         return out
 
     def take_workspace(self, device):
