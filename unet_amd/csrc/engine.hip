@@ -634,8 +634,13 @@ bool build(mi_unet& u) {
                 StencilParams& p = s.stn;
                 REL(s, p, in, B_ARENA, U.actT.off);
                 REL(s, p, dout, B_DLOGITS, 0);
-                p.nsplit = 128; p.ndim = nd; p.nb = nb;
+                p.ndim = nd; p.nb = nb;
                 for (int d = 0; d < 3; ++d) p.d[d] = u.rd[0][d];
+                {
+                    const long long items = (long long)nb * u.rp[0] / (p.d[2] % 4 == 0 ? 4 : 1);
+                    long long blocks = (items + 255) / 256;
+                    p.nsplit = (int)(blocks < 1 ? 1 : blocks > 1024 ? 1024 : blocks);
+                }
                 po = B.alloc((size_t)p.nsplit * KK * sizeof(float)); pb = B.alloc((size_t)p.nsplit * sizeof(float));
                 REL(s, p, partial, B_ARENA, po); REL(s, p, partial_bias, B_ARENA, pb);
                 s.kernel = "stencil_wgrad_kernel";
@@ -661,8 +666,9 @@ bool build(mi_unet& u) {
                 C1Params& p = s.c1;
                 REL(s, p, y, B_ARENA, cat[0].off); p.y_pitch = K; p.y_coff = 0; p.N = K;
                 REL(s, p, x1, B_ARENA, g_rawT.off);
-                p.ndim = nd; p.nb = nb; p.nsplit = 256;
+                p.ndim = nd; p.nb = nb; p.n_y1 = K;
                 for (int d = 0; d < 3; ++d) { p.fd[d] = u.rd[0][d]; p.cd[d] = u.rd[1][d]; }
+                p.nsplit = c1_wgrad_slabs(p.N, p.cd);
                 po = B.alloc((size_t)p.nsplit * KK * K * sizeof(float)); pb = B.alloc((size_t)p.nsplit * K * sizeof(float));
                 REL(s, p, partial, B_ARENA, po); REL(s, p, partial_bias, B_ARENA, pb);
                 s.kernel = dt ? "c1_s2_wgrad_kernel<BF16>" : "c1_s2_wgrad_kernel<F32>";
@@ -801,21 +807,25 @@ bool build(mi_unet& u) {
                 B.add_reduce(po, pb, nslab, nt, 2 * cout, cin, 0, cout, KK, nat, D.un[0].wname, D.un[0].bname);
                 B.add_reduce(po, pb, nslab, nt, 2 * cout, cin, cout, cout, KK, nat, P + ".residual.weight", P + ".residual.bias");
             } else {
-                for (int half = 0; half < 2; ++half) {
-                    Step& s = B.push(u.bwd, K_C1_WGRAD, half == 0 ? "down0.unit0 conv wgrad" : "down0.residual conv wgrad");
+                {
+                    // unit0 (gradient of the raw conv output) and the residual conv (gradient of the block output)
+                    // share the input image: one launch, two gradient sources
+                    Step& s = B.push(u.bwd, K_C1_WGRAD, "down0.unit0+residual conv wgrad");
                     C1Params& p = s.c1;
-                    const Ten& y = half == 0 ? g_raw : dout;
-                    REL(s, p, y, B_ARENA, y.off); p.y_pitch = y.pitch; p.y_coff = y.coff; p.N = cout;
+                    REL(s, p, y, B_ARENA, g_raw.off); p.y_pitch = g_raw.pitch; p.y_coff = g_raw.coff;
+                    REL(s, p, y2, B_ARENA, dout.off); p.y2_pitch = dout.pitch; p.y2_coff = dout.coff;
+                    p.N = 2 * cout; p.n_y1 = cout;
                     REL(s, p, x1, B_XIN, 0);
-                    p.ndim = nd; p.nb = nb; p.nsplit = 256;
+                    p.ndim = nd; p.nb = nb;
                     for (int d = 0; d < 3; ++d) { p.fd[d] = u.rd[0][d]; p.cd[d] = u.rd[1][d]; }
-                    po = B.alloc((size_t)p.nsplit * KK * cout * sizeof(float)); pb = B.alloc((size_t)p.nsplit * cout * sizeof(float));
+                    p.nsplit = c1_wgrad_slabs(p.N, p.cd);
+                    po = B.alloc((size_t)p.nsplit * KK * 2 * cout * sizeof(float)); pb = B.alloc((size_t)p.nsplit * 2 * cout * sizeof(float));
                     REL(s, p, partial, B_ARENA, po); REL(s, p, partial_bias, B_ARENA, pb);
                     s.kernel = dt ? "c1_s2_wgrad_kernel<BF16>" : "c1_s2_wgrad_kernel<F32>";
-                    s.work = (double)nb * (u.rp[0] * 4.0 + u.rp[1] * (double)cout * esz);
-                    u.flops_bwd += 2.0 * nb * u.rp[1] * KK * (double)cout;
-                    if (half == 0) B.add_reduce(po, pb, p.nsplit, KK, cout, 1, 0, cout, KK, nat, D.un[0].wname, D.un[0].bname);
-                    else B.add_reduce(po, pb, p.nsplit, KK, cout, 1, 0, cout, KK, nat, P + ".residual.weight", P + ".residual.bias");
+                    s.work = (double)nb * (u.rp[0] * 4.0 + u.rp[1] * 2.0 * cout * esz);
+                    u.flops_bwd += 2.0 * nb * u.rp[1] * KK * 2.0 * cout;
+                    B.add_reduce(po, pb, p.nsplit, KK, 2 * cout, 1, 0, cout, KK, nat, D.un[0].wname, D.un[0].bname);
+                    B.add_reduce(po, pb, p.nsplit, KK, 2 * cout, 1, cout, cout, KK, nat, P + ".residual.weight", P + ".residual.bias");
                 }
             }
         }

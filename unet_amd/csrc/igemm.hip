@@ -482,8 +482,7 @@ __device__ __forceinline__ void reduce_body(const ReduceDesc& d);
 template <class TR>
 __device__ __forceinline__ void pack_body(const PackDesc& d);
 __global__ __launch_bounds__(256) void reduce_kernel(const ReduceDesc* __restrict__ descs) {
-    const ReduceDesc d = descs[blockIdx.y];
-    reduce_body(d);
+    reduce_body(descs[blockIdx.y]);
 }
 template <class TR>
 __global__ __launch_bounds__(256) void pack_kernel(const PackDesc* __restrict__ descs) {
@@ -491,39 +490,53 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackDesc* __restrict__ 
     pack_body<TR>(d);
 }
 
-// 256 threads = 64 output elements x 4 slab groups; each thread sums its slabs in order, the four group
-// sums are combined in a fixed order through LDS (bitwise reproducible).
+// 256 threads = EL output elements x SG slab groups (EL = 64, 16, 4 or 1: few outputs with many slabs get more
+// slab groups).  Each thread sums its slabs in slab order with eight loads in flight, the group sums are
+// combined by a fixed-shape tree through LDS, so the result is bitwise reproducible.
 __device__ __forceinline__ void reduce_body(const ReduceDesc& d) {
-    __shared__ float part[4][64];
+    __shared__ float part[256];
     const int nw = d.ntaps * d.Fcnt * d.S;
     const int total = nw + (d.dst_b ? d.Fcnt : 0);
-    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    const int EL = total >= 2048 ? 64 : total >= 256 ? 16 : total >= 16 ? 4 : 1;
+    const int SG = 256 / EL;
+    const int lx = threadIdx.x % EL, ly = threadIdx.x / EL;
+    const int nslab = d.nslab;
     const size_t stride = (size_t)d.ntaps * d.Ftot * d.S;
-    for (int base = blockIdx.x * 64; base < total; base += gridDim.x * 64) {
+    for (int base = blockIdx.x * EL; base < total; base += gridDim.x * EL) {
         const int i = base + lx;
         float a = 0.f;
         int s = 0, f = 0, t = 0;
+        const float* src = nullptr;
+        size_t st = 0;
         if (i < nw) {
             s = i % d.S; const int r = i / d.S;
             f = r % d.Fcnt; t = r / d.Fcnt;
-            const size_t off = ((size_t)t * d.Ftot + d.f_off + f) * d.S + s;
-            int sl = ly;
-            for (; sl + 28 < d.nslab; sl += 32) {   // eight independent loads in flight, summed in slab order
-                const float v0 = d.partial[(size_t)sl * stride + off], v1 = d.partial[(size_t)(sl + 4) * stride + off];
-                const float v2 = d.partial[(size_t)(sl + 8) * stride + off], v3 = d.partial[(size_t)(sl + 12) * stride + off];
-                const float v4 = d.partial[(size_t)(sl + 16) * stride + off], v5 = d.partial[(size_t)(sl + 20) * stride + off];
-                const float v6 = d.partial[(size_t)(sl + 24) * stride + off], v7 = d.partial[(size_t)(sl + 28) * stride + off];
-                a = (((((((a + v0) + v1) + v2) + v3) + v4) + v5) + v6) + v7;
-            }
-            for (; sl < d.nslab; sl += 4) a += d.partial[(size_t)sl * stride + off];
+            src = d.partial + ((size_t)t * d.Ftot + d.f_off + f) * d.S + s;
+            st = stride;
         } else if (i < total) {
             f = i - nw;
-            for (int sl = ly; sl < d.nslab; sl += 4) a += d.partial_bias[(size_t)sl * d.Ftot + d.f_off + f];
+            src = d.partial_bias + d.f_off + f;
+            st = (size_t)d.Ftot;
         }
-        part[ly][lx] = a;
+        if (src) {
+            int sl = ly;
+            for (; sl + 7 * SG < nslab; sl += 8 * SG) {
+                const float v0 = src[(size_t)sl * st], v1 = src[(size_t)(sl + SG) * st];
+                const float v2 = src[(size_t)(sl + 2 * SG) * st], v3 = src[(size_t)(sl + 3 * SG) * st];
+                const float v4 = src[(size_t)(sl + 4 * SG) * st], v5 = src[(size_t)(sl + 5 * SG) * st];
+                const float v6 = src[(size_t)(sl + 6 * SG) * st], v7 = src[(size_t)(sl + 7 * SG) * st];
+                a = (((((((a + v0) + v1) + v2) + v3) + v4) + v5) + v6) + v7;
+            }
+            for (; sl < nslab; sl += SG) a += src[(size_t)sl * st];
+        }
+        part[ly * EL + lx] = a;
         __syncthreads();
+        for (int step = SG >> 1; step >= 1; step >>= 1) {
+            if (ly < step) part[ly * EL + lx] += part[(ly + step) * EL + lx];
+            __syncthreads();
+        }
         if (ly == 0 && i < total) {
-            const float v = ((part[0][lx] + part[1][lx]) + part[2][lx]) + part[3][lx];
+            const float v = part[lx];
             if (i < nw) d.dst_w[((size_t)f * d.S + s) * d.KK + d.kidx[t]] = v;
             else d.dst_b[f] = v;
         }

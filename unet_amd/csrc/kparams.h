@@ -94,6 +94,8 @@ struct C1Params {
     const float* x1; float* x1_out;         // fine one-channel tensor (input / output)
     const char* y; char* y_out;             // coarse N-channel tensor (input / output)
     int y_pitch, y_coff, N;
+    const char* y2; int y2_pitch, y2_coff;  // weight gradient: channels >= n_y1 are read from this tensor
+    int n_y1;
     const float* w; const float* w2; int n_w1;  // weights [n][KK]; channels >= n_w1 read w2[(n-n_w1)][KK]
     const float* bias; int bias_c0;
     double* stats; int stats_c, nstat;
@@ -118,6 +120,7 @@ int launch_wgrad(int dtype, const WgradParams& p, hipStream_t st);
 int launch_reduce(const ReduceDesc* d_descs, int ndesc, int max_elems, hipStream_t st);
 int launch_pack(int dtype, const PackDesc* d_descs, int ndesc, int max_elems, hipStream_t st);
 int launch_reduce_one(const ReduceDesc& d, hipStream_t st);
+int c1_wgrad_slabs(int N, const int cd[3]);
 int launch_pack_one(int dtype, const PackDesc& d, hipStream_t st);
 int launch_norm_fwd(int dtype, const NormParams& p, hipStream_t st);
 int launch_norm_bwd(int dtype, const NormParams& p, hipStream_t st);

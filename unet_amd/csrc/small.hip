@@ -8,142 +8,208 @@
 namespace {
 
 // ---- 1 -> N stride-2 convolution (k=3, pad=1), fine one-channel -> coarse N-channel ------
-template <class TR>
+// Thread = (coarse column, group of 8 output channels); a workgroup covers ppb = 256/(N/8) columns x ROWS rows.
+// The 72 weights of a kz plane sit in registers, the (2*ROWS+1) x 3 input values of the thread's column are
+// loaded up front (independent loads), and each thread keeps running sums for the norm statistics.
+template <class TR, int KZ>
 __global__ __launch_bounds__(256) void c1_s2_fwd_kernel(const C1Params p) {
     constexpr int ESZ = TR::ESZ;
-    extern __shared__ __attribute__((aligned(16))) float sm[];  // weights [N][KK], then partials [2][ppb][N]
-    const int KZ = p.ndim == 3 ? 3 : 1;
-    const int KK = KZ * 9;
-    const int G = p.N / 8;
-    const int img = blockIdx.y;
+    constexpr int KK = KZ * 9;
+    constexpr int ROWS = 4;
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // weights [KK][N], then partials [2][ppb][N]
+    const int N = p.N;
+    const int G = N / 8;
+    const int ppb = 256 / G;
     float* wl = sm;
-    float* sst = sm + p.N * KK;
-    for (int i = threadIdx.x; i < p.N * KK; i += 256) {
+    float* sst = sm + N * KK;
+    for (int i = threadIdx.x; i < N * KK; i += 256) {
         const int n = i / KK, k = i - n * KK;
-        wl[i] = (n < p.n_w1) ? p.w[n * KK + k] : p.w2[(n - p.n_w1) * KK + k];
+        wl[k * N + n] = (n < p.n_w1) ? p.w[n * KK + k] : p.w2[(n - p.n_w1) * KK + k];
     }
     __syncthreads();
-    const int cpix = p.cd[0] * p.cd[1] * p.cd[2];
     const int grp = threadIdx.x % G, pl = threadIdx.x / G;
-    const int ppb = 256 / G;
-    const int pix = blockIdx.x * ppb + pl;
-    const bool valid = pl < ppb && pix < cpix;
-    float acc[8];
+    const int cz = blockIdx.z % p.cd[0], img = blockIdx.z / p.cd[0];
+    const int cy0 = blockIdx.y * ROWS;
+    const int cx = blockIdx.x * ppb + pl;
+    const bool lane_ok = pl < ppb && cx < p.cd[2];
+    const size_t fpix = (size_t)p.fd[0] * p.fd[1] * p.fd[2];
+    const size_t cpix = (size_t)p.cd[0] * p.cd[1] * p.cd[2];
+    const float* xin = p.x1 + (size_t)img * fpix;
+    float acc[ROWS][8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    if (valid) {
-        const int cx = pix % p.cd[2]; const int r = pix / p.cd[2];
-        const int cy = r % p.cd[1]; const int cz = r / p.cd[1];
-        const float* xin = p.x1 + (size_t)img * p.fd[0] * p.fd[1] * p.fd[2];
-        for (int kz = 0; kz < KZ; ++kz) {
-            const int fz = (p.ndim == 3) ? 2 * cz - 1 + kz : 0;
-            if ((unsigned)fz >= (unsigned)p.fd[0]) continue;
-            for (int ky = 0; ky < 3; ++ky) {
-                const int fy = 2 * cy - 1 + ky;
-                if ((unsigned)fy >= (unsigned)p.fd[1]) continue;
+    for (int r = 0; r < ROWS; ++r)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int fx = 2 * cx - 1 + kx;
-                    if ((unsigned)fx >= (unsigned)p.fd[2]) continue;
-                    const float xv = xin[((size_t)fz * p.fd[1] + fy) * p.fd[2] + fx];
-                    const int k = (kz * 3 + ky) * 3 + kx;
+        for (int e = 0; e < 8; ++e) acc[r][e] = 0.f;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[e] += xv * wl[(grp * 8 + e) * KK + k];
-                }
+    for (int kz = 0; kz < KZ; ++kz) {
+        const int fz = (KZ == 3) ? 2 * cz - 1 + kz : 0;
+        if ((unsigned)fz >= (unsigned)p.fd[0]) continue;   // uniform over the workgroup
+        float wr[9][8];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const float4 a = *reinterpret_cast<const float4*>(wl + (kz * 9 + k) * N + grp * 8);
+            const float4 b = *reinterpret_cast<const float4*>(wl + (kz * 9 + k) * N + grp * 8 + 4);
+            wr[k][0] = a.x; wr[k][1] = a.y; wr[k][2] = a.z; wr[k][3] = a.w;
+            wr[k][4] = b.x; wr[k][5] = b.y; wr[k][6] = b.z; wr[k][7] = b.w;
+        }
+        float xr[2 * ROWS + 1][3];
+#pragma unroll
+        for (int j = 0; j < 2 * ROWS + 1; ++j) {
+            const int fy = 2 * cy0 - 1 + j;
+            const bool rok = lane_ok && (unsigned)fy < (unsigned)p.fd[1];
+            const float* row = xin + ((size_t)fz * p.fd[1] + (rok ? fy : 0)) * p.fd[2];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int fx = 2 * cx - 1 + kx;
+                xr[j][kx] = (rok && (unsigned)fx < (unsigned)p.fd[2]) ? row[fx] : 0.f;
             }
         }
-        float o[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int ch = grp * 8 + e;
-            o[e] = acc[e] + ((p.bias && ch >= p.bias_c0) ? p.bias[ch - p.bias_c0] : 0.f);
+        for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float xv = xr[2 * r + ky][kx];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[r][e] += xv * wr[ky * 3 + kx][e];
+                }
+    }
+    float bv[8], s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ch = grp * 8 + e;
+        bv[e] = (p.bias && ch >= p.bias_c0 && pl < ppb) ? p.bias[ch - p.bias_c0] : 0.f;
+        s1[e] = 0.f; s2[e] = 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int cy = cy0 + r;
+        if (lane_ok && cy < p.cd[1]) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                o[e] = acc[r][e] + bv[e];
+                s1[e] += acc[r][e];
+                s2[e] += acc[r][e] * acc[r][e];
+            }
+            const size_t gp = (size_t)img * cpix + ((size_t)cz * p.cd[1] + cy) * p.cd[2] + cx;
+            store_n<TR, 8>(p.y_out + (gp * p.y_pitch + p.y_coff + grp * 8) * ESZ, o);
         }
-        const size_t gp = (size_t)img * cpix + pix;
-        store_n<TR, 8>(p.y_out + (gp * p.y_pitch + p.y_coff + grp * 8) * ESZ, o);
     }
     if (p.stats) {
-        // fixed-order reduction over the workgroup's pixels, then fp64 accumulators
+        // fixed-order reduction over the workgroup's columns, then fp64 accumulators
         if (pl < ppb) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float v = valid ? acc[e] : 0.f;
-                sst[pl * p.N + grp * 8 + e] = v;
-                sst[(ppb + pl) * p.N + grp * 8 + e] = v * v;
+                sst[pl * N + grp * 8 + e] = s1[e];
+                sst[(ppb + pl) * N + grp * 8 + e] = s2[e];
             }
         }
         __syncthreads();
-        const int slot = blockIdx.x % MI_NSLOT;
+        const int slot = (blockIdx.x + blockIdx.y) % MI_NSLOT;
         for (int i = threadIdx.x; i < p.nstat * 2; i += 256) {
             const int ch = i >> 1, k = i & 1;
             float a = 0.f;
-            for (int r = 0; r < ppb; ++r) a += sst[(k * ppb + r) * p.N + ch];
+            for (int r = 0; r < ppb; ++r) a += sst[(k * ppb + r) * N + ch];
             atomicAdd(&p.stats[(((size_t)img * MI_NSLOT + slot) * p.stats_c) * 2 + i], (double)a);
         }
     }
 }
 
 // ---- N -> 1 stride-2 transposed convolution (k=3, pad=1, output_padding=1) ---------------
-template <class TR>
+// Phase 1: every coarse pixel of the tile (plus a one-pixel halo on the high side) forms its KK tap
+// products d[k] = <Y[c][:], w[:][k]> once and parks them in LDS.  Phase 2: every fine pixel sums the
+// 1, 2, 4 (or 8) products that land on it: per dimension an even fine index takes tap 1 of its own
+// coarse pixel, an odd one takes tap 2 of its own and tap 0 of the next coarse pixel.
+template <class TR, int KZ>
 __global__ __launch_bounds__(256) void c1_s2_T_kernel(const C1Params p) {
     constexpr int ESZ = TR::ESZ;
-    extern __shared__ __attribute__((aligned(16))) float sm[];  // weights transposed [KK][N]
+    constexpr int KK = KZ * 9;
+    constexpr int TZ = KZ == 3 ? 4 : 1, TY = 8, TX = KZ == 3 ? 8 : 32;
+    constexpr int PZ = KZ == 3 ? TZ + 1 : 1, PY = TY + 1, PX = TX + 1, NP = PZ * PY * PX;
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // weights [KK][N], then products [KK][NP]
     __shared__ float red[2][4];
-    const int KZ = p.ndim == 3 ? 3 : 1;
-    const int KK = KZ * 9;
-    const int img = blockIdx.y;
-    for (int i = threadIdx.x; i < p.N * KK; i += 256) {
+    const int N = p.N;
+    float* wl = sm;
+    float* D = sm + KK * N;
+    for (int i = threadIdx.x; i < N * KK; i += 256) {
         const int n = i / KK, k = i - n * KK;
-        sm[k * p.N + n] = p.w[i];
+        wl[k * N + n] = p.w[i];
     }
     __syncthreads();
-    const int fpix = p.fd[0] * p.fd[1] * p.fd[2];
-    const int cpix = p.cd[0] * p.cd[1] * p.cd[2];
-    const int pix = blockIdx.x * 256 + threadIdx.x;
-    float acc = 0.f;
-    const bool valid = pix < fpix;
-    if (valid) {
-        const int fx = pix % p.fd[2]; const int r = pix / p.fd[2];
-        const int fy = r % p.fd[1]; const int fz = r / p.fd[1];
-        // per dim: even f -> (k=1, c=f/2); odd f -> (k=0, c=(f+1)/2) and (k=2, c=(f-1)/2)
-        int kzs[2], czs[2], nz = 0, kys[2], cys[2], ny = 0, kxs[2], cxs[2], nx = 0;
-        if (p.ndim == 3) {
-            if (fz & 1) {
-                if ((fz + 1) / 2 < p.cd[0]) { kzs[nz] = 0; czs[nz++] = (fz + 1) / 2; }
-                kzs[nz] = 2; czs[nz++] = (fz - 1) / 2;
-            } else { kzs[nz] = 1; czs[nz++] = fz / 2; }
-        } else { kzs[0] = 0; czs[0] = 0; nz = 1; }
-        if (fy & 1) {
-            if ((fy + 1) / 2 < p.cd[1]) { kys[ny] = 0; cys[ny++] = (fy + 1) / 2; }
-            kys[ny] = 2; cys[ny++] = (fy - 1) / 2;
-        } else { kys[ny] = 1; cys[ny++] = fy / 2; }
-        if (fx & 1) {
-            if ((fx + 1) / 2 < p.cd[2]) { kxs[nx] = 0; cxs[nx++] = (fx + 1) / 2; }
-            kxs[nx] = 2; cxs[nx++] = (fx - 1) / 2;
-        } else { kxs[nx] = 1; cxs[nx++] = fx / 2; }
-        for (int a = 0; a < nz; ++a)
-            for (int b = 0; b < ny; ++b)
-                for (int c = 0; c < nx; ++c) {
-                    const int k = (kzs[a] * 3 + kys[b]) * 3 + kxs[c];
-                    const size_t gp = (size_t)img * cpix + ((size_t)czs[a] * p.cd[1] + cys[b]) * p.cd[2] + cxs[c];
-                    const char* src = p.y + (gp * p.y_pitch + p.y_coff) * ESZ;
-                    const float* wk = sm + k * p.N;
-                    for (int n0 = 0; n0 < p.N; n0 += 8) {
-                        float v[8];
-                        load_n<TR, 8>(src + n0 * ESZ, v);
+    const int tzn = (p.cd[0] + TZ - 1) / TZ;
+    const int img = blockIdx.z / tzn;
+    const int cz0 = (blockIdx.z % tzn) * TZ, cy0 = blockIdx.y * TY, cx0 = blockIdx.x * TX;
+    const size_t cpix = (size_t)p.cd[0] * p.cd[1] * p.cd[2];
+    const size_t fpix = (size_t)p.fd[0] * p.fd[1] * p.fd[2];
+    for (int i = threadIdx.x; i < NP; i += 256) {
+        const int px = i % PX; const int r = i / PX;
+        const int py = r % PY, pz = r / PY;
+        const int cz = cz0 + pz, cy = cy0 + py, cx = cx0 + px;
+        float d[KK];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) acc += v[e] * wk[n0 + e];
-                    }
+        for (int k = 0; k < KK; ++k) d[k] = 0.f;
+        if (cz < p.cd[0] && cy < p.cd[1] && cx < p.cd[2]) {
+            const size_t gp = (size_t)img * cpix + ((size_t)cz * p.cd[1] + cy) * p.cd[2] + cx;
+            const char* src = p.y + (gp * p.y_pitch + p.y_coff) * ESZ;
+            for (int n0 = 0; n0 < N; n0 += 8) {
+                float v[8];
+                load_n<TR, 8>(src + n0 * ESZ, v);
+#pragma unroll
+                for (int k = 0; k < KK; ++k) {
+                    const float4 a = *reinterpret_cast<const float4*>(wl + k * N + n0);
+                    const float4 b = *reinterpret_cast<const float4*>(wl + k * N + n0 + 4);
+                    d[k] += v[0] * a.x + v[1] * a.y + v[2] * a.z + v[3] * a.w + v[4] * b.x + v[5] * b.y + v[6] * b.z + v[7] * b.w;
                 }
-        p.x1_out[(size_t)img * fpix + pix] = acc + (p.bias ? p.bias[0] : 0.f);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KK; ++k) D[k * NP + i] = d[k];
+    }
+    __syncthreads();
+    const int tx = threadIdx.x % TX, ty = (threadIdx.x / TX) % TY, tz = threadIdx.x / (TX * TY);
+    const int cz = cz0 + tz, cy = cy0 + ty, cx = cx0 + tx;
+    const bool valid = cz < p.cd[0] && cy < p.cd[1] && cx < p.cd[2];
+    const float bias = p.bias ? p.bias[0] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    if (valid) {
+        float* out = p.x1_out + (size_t)img * fpix;
+#pragma unroll
+        for (int pz = 0; pz < (KZ == 3 ? 2 : 1); ++pz)
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+                float o[2];
+#pragma unroll
+                for (int px = 0; px < 2; ++px) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int az = 0; az <= ((KZ == 3) ? pz : 0); ++az)
+#pragma unroll
+                        for (int ay = 0; ay <= py; ++ay)
+#pragma unroll
+                            for (int ax = 0; ax <= px; ++ax) {
+                                // parity 0: (tap 1, own pixel); parity 1: a = 0 -> (tap 2, own), a = 1 -> (tap 0, next)
+                                const int kz = (KZ == 3) ? (pz == 0 ? 1 : (az == 0 ? 2 : 0)) : 0;
+                                const int ky = py == 0 ? 1 : (ay == 0 ? 2 : 0);
+                                const int kx = px == 0 ? 1 : (ax == 0 ? 2 : 0);
+                                const int k = (kz * 3 + ky) * 3 + kx;
+                                acc += D[k * NP + ((tz + az) * PY + ty + ay) * PX + tx + ax];
+                            }
+                    o[px] = acc;
+                    s1 += acc; s2 += acc * acc;
+                }
+                const size_t fo = ((size_t)(2 * cz + pz) * p.fd[1] + 2 * cy + py) * p.fd[2] + 2 * cx;
+                *reinterpret_cast<float2*>(out + fo) = make_float2(o[0] + bias, o[1] + bias);
+            }
     }
     if (p.stats) {
-        float a = valid ? acc : 0.f, b = a * a;
-        a = wave_sum(a); b = wave_sum(b);
+        s1 = wave_sum(s1); s2 = wave_sum(s2);
         const int w = threadIdx.x >> 6;
-        if ((threadIdx.x & 63) == 0) { red[0][w] = a; red[1][w] = b; }
+        if ((threadIdx.x & 63) == 0) { red[0][w] = s1; red[1][w] = s2; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            const int slot = blockIdx.x % MI_NSLOT;
+            const int slot = (blockIdx.x + blockIdx.y) % MI_NSLOT;
             atomicAdd(&p.stats[((size_t)img * MI_NSLOT + slot) * 2], (double)(((red[0][0] + red[0][1]) + red[0][2]) + red[0][3]));
             atomicAdd(&p.stats[((size_t)img * MI_NSLOT + slot) * 2 + 1], (double)(((red[1][0] + red[1][1]) + red[1][2]) + red[1][3]));
         }
@@ -151,7 +217,9 @@ __global__ __launch_bounds__(256) void c1_s2_T_kernel(const C1Params p) {
 }
 
 // ---- weight gradient of both: partial[slab][k][n] = sum_c Y[c][n] * x1[2c-1+k] ;
-//      partial_bias[slab][n] = sum_c Y[c][n].  blockIdx.y = kz plane in 3-D. ----------------
+//      partial_bias[slab][n] = sum_c Y[c][n].  blockIdx.y = kz plane in 3-D.
+// Thread = (coarse column, group of 8 channels); blockIdx.x = (column block, row block), the row block strides
+// over all (image, z, y) rows so that no per-lane division is needed.  Channels >= n_y1 come from y2.
 template <class TR>
 __global__ __launch_bounds__(256) void c1_s2_wgrad_kernel(const C1Params p) {
     constexpr int ESZ = TR::ESZ;
@@ -162,9 +230,8 @@ __global__ __launch_bounds__(256) void c1_s2_wgrad_kernel(const C1Params p) {
     const int G = p.N / 8;
     for (int i = threadIdx.x; i < 4 * p.N * 10; i += 256) sm[i] = 0.f;
     __syncthreads();
-    const int cpix = p.cd[0] * p.cd[1] * p.cd[2];
-    const int fpix = p.fd[0] * p.fd[1] * p.fd[2];
-    const long long items = (long long)p.nb * cpix * G;
+    const size_t cpix = (size_t)p.cd[0] * p.cd[1] * p.cd[2];
+    const size_t fpix = (size_t)p.fd[0] * p.fd[1] * p.fd[2];
     float acc[8][9], accb[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -173,32 +240,45 @@ __global__ __launch_bounds__(256) void c1_s2_wgrad_kernel(const C1Params p) {
         for (int k = 0; k < 9; ++k) acc[e][k] = 0.f;
     }
     const int grp = threadIdx.x % G, pl = threadIdx.x / G;
-    const int ppb = 256 / G;  // (pixel, channel group) pairs per sweep; the group of a thread never changes
-    const long long npx = items / G;
-    for (long long gp = (long long)blockIdx.x * ppb + pl; pl < ppb && gp < npx; gp += (long long)gridDim.x * ppb) {
-        const int img = (int)(gp / cpix); const int pix = (int)(gp - (long long)img * cpix);
-        const int cx = pix % p.cd[2]; const int r = pix / p.cd[2];
-        const int cy = r % p.cd[1]; const int cz = r / p.cd[1];
+    const int ppb = 256 / G;
+    const int xblocks = (p.cd[2] + ppb - 1) / ppb;
+    const int xb = blockIdx.x % xblocks, rb = blockIdx.x / xblocks, nrb = gridDim.x / xblocks;
+    const int cx = xb * ppb + pl;
+    const bool lane_ok = pl < ppb && cx < p.cd[2];
+    const bool second = grp * 8 >= p.n_y1;
+    const char* ysrc = second ? p.y2 : p.y;
+    const int ypitch = second ? p.y2_pitch : p.y_pitch;
+    const int ych = second ? p.y2_coff + grp * 8 - p.n_y1 : p.y_coff + grp * 8;
+    const int nrows = p.nb * p.cd[0] * p.cd[1];
+    if (rb < nrb)   // workgroups beyond the last full row block (grid not a multiple of xblocks) only write zeros
+    for (int row = rb; row < nrows; row += nrb) {
+        const int cy = row % p.cd[1]; const int r2 = row / p.cd[1];
+        const int cz = r2 % p.cd[0]; const int img = r2 / p.cd[0];
+        if (!lane_ok) continue;
         float v[8];
-        load_n<TR, 8>(p.y + ((size_t)gp * p.y_pitch + p.y_coff + grp * 8) * ESZ, v);
+        load_n<TR, 8>(ysrc + (((size_t)row * p.cd[2] + cx) * ypitch + ych) * ESZ, v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) accb[e] += v[e];
         const int fz = (p.ndim == 3) ? 2 * cz - 1 + kz : 0;
         if ((unsigned)fz >= (unsigned)p.fd[0]) continue;
         const float* xin = p.x1 + (size_t)img * fpix + (size_t)fz * p.fd[1] * p.fd[2];
+        float xv[9];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int fy = 2 * cy - 1 + ky;
+            const bool rok = (unsigned)fy < (unsigned)p.fd[1];
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int fx = 2 * cx - 1 + kx;
-                float xv = 0.f;
-                if ((unsigned)fy < (unsigned)p.fd[1] && (unsigned)fx < (unsigned)p.fd[2]) xv = xin[(size_t)fy * p.fd[2] + fx];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e][ky * 3 + kx] += v[e] * xv;
+                xv[ky * 3 + kx] = (rok && (unsigned)fx < (unsigned)p.fd[2]) ? xin[(size_t)fy * p.fd[2] + fx] : 0.f;
             }
         }
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e][k] += v[e] * xv[k];
     }
+    (void)cpix;
     // lanes that share a channel group: xor-reduce over lane bits >= log2(G) when G divides the wave
     const bool pow2 = (64 % G) == 0;
     if (pow2) {
@@ -251,7 +331,52 @@ __global__ __launch_bounds__(256) void c1_s2_wgrad_kernel(const C1Params p) {
 }
 
 // ---- one-channel 3^d stencil: out = sum_k w[k] * in[p + k - 1] + bias + addend ------------
+// Thread = four consecutive pixels of a row (one aligned 16-byte load per stencil row plus the two
+// neighbours); needs a row length that is a multiple of 4.
+template <int KZ>
 __global__ __launch_bounds__(256) void stencil_kernel(const StencilParams p) {
+    constexpr int KK = KZ * 9;
+    const int qrow = p.d[2] >> 2;
+    const long long nq = (long long)p.d[0] * p.d[1] * qrow;
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    const int img = blockIdx.y;
+    const size_t npix = (size_t)p.d[0] * p.d[1] * p.d[2];
+    const int x0 = (int)(q % qrow) * 4; const int r = (int)(q / qrow);
+    const int y = r % p.d[1]; const int z = r / p.d[1];
+    const float* in = p.in + (size_t)img * npix;
+    float w[KK];
+#pragma unroll
+    for (int k = 0; k < KK; ++k) w[k] = p.w[p.flip ? KK - 1 - k : k];
+    const float b = p.bias ? p.bias[0] : 0.f;
+    float acc[4] = {b, b, b, b};
+#pragma unroll
+    for (int kz = 0; kz < KZ; ++kz) {
+        const int zz = (KZ == 3) ? z - 1 + kz : 0;
+        if ((unsigned)zz >= (unsigned)p.d[0]) continue;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yy = y - 1 + ky;
+            if ((unsigned)yy >= (unsigned)p.d[1]) continue;
+            const float* row = in + ((size_t)zz * p.d[1] + yy) * p.d[2];
+            const float4 c = *reinterpret_cast<const float4*>(row + x0);
+            const float v[6] = {x0 > 0 ? row[x0 - 1] : 0.f, c.x, c.y, c.z, c.w, x0 + 4 < p.d[2] ? row[x0 + 4] : 0.f};
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] += w[(kz * 3 + ky) * 3 + kx] * v[j + kx];
+        }
+    }
+    const size_t o = (size_t)img * npix + ((size_t)z * p.d[1] + y) * p.d[2] + x0;
+    if (p.addend) {
+        const float4 a = *reinterpret_cast<const float4*>(p.addend + o);
+        acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+    }
+    *reinterpret_cast<float4*>(p.out + o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
+// any row length: one pixel per thread
+__global__ __launch_bounds__(256) void stencil_scalar_kernel(const StencilParams p) {
     const int KZ = p.ndim == 3 ? 3 : 1;
     const int KK = KZ * 9;
     const int img = blockIdx.y;
@@ -283,35 +408,53 @@ __global__ __launch_bounds__(256) void stencil_kernel(const StencilParams p) {
 }
 
 // partial[slab][k] = sum_p in[p + k - 1] * dout[p];  partial_bias[slab] = sum_p dout[p]
+// QUAD = 4: four consecutive pixels per thread and iteration (row length a multiple of 4); QUAD = 1: any length.
+template <int QUAD>
 __global__ __launch_bounds__(256) void stencil_wgrad_kernel(const StencilParams p) {
     __shared__ float red[10][4];
     const int KZ = p.ndim == 3 ? 3 : 1;
     const int KK = KZ * 9;
     const int kz = blockIdx.y;
-    const int npix = p.d[0] * p.d[1] * p.d[2];
-    const long long total = (long long)p.nb * npix;
+    const int qrow = p.d[2] / QUAD;
+    const long long rows = (long long)p.nb * p.d[0] * p.d[1];
+    const long long total = rows * qrow;
     float acc[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) acc[k] = 0.f;
     for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long long)gridDim.x * 256) {
-        const int img = (int)(it / npix); const int pix = (int)(it - (long long)img * npix);
-        const int x = pix % p.d[2]; const int r = pix / p.d[2];
-        const int y = r % p.d[1]; const int z = r / p.d[1];
-        const float g = p.dout[it];
-        acc[9] += g;
+        const int x0 = (int)(it % qrow) * QUAD; const long long row = it / qrow;
+        const int y = (int)(row % p.d[1]); const long long r2 = row / p.d[1];
+        const int z = (int)(r2 % p.d[0]);
+        float g[QUAD];
+        if constexpr (QUAD == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(p.dout + row * p.d[2] + x0);
+            g[0] = t.x; g[1] = t.y; g[2] = t.z; g[3] = t.w;
+        } else {
+            g[0] = p.dout[row * p.d[2] + x0];
+        }
+#pragma unroll
+        for (int j = 0; j < QUAD; ++j) acc[9] += g[j];
         const int zz = (p.ndim == 3) ? z - 1 + kz : 0;
         if ((unsigned)zz >= (unsigned)p.d[0]) continue;
-        const float* in = p.in + (size_t)img * npix + (size_t)zz * p.d[1] * p.d[2];
+        const float* in = p.in + (row + (long long)(zz - z) * p.d[1] - y) * p.d[2];   // row 0 of plane zz of this image
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int yy = y - 1 + ky;
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int xx = x - 1 + kx;
-                float v = 0.f;
-                if ((unsigned)yy < (unsigned)p.d[1] && (unsigned)xx < (unsigned)p.d[2]) v = in[(size_t)yy * p.d[2] + xx];
-                acc[ky * 3 + kx] += v * g;
+            if ((unsigned)yy >= (unsigned)p.d[1]) continue;
+            const float* rp = in + (size_t)yy * p.d[2];
+            float v[QUAD + 2];
+            v[0] = x0 > 0 ? rp[x0 - 1] : 0.f;
+            if constexpr (QUAD == 4) {
+                const float4 c = *reinterpret_cast<const float4*>(rp + x0);
+                v[1] = c.x; v[2] = c.y; v[3] = c.z; v[4] = c.w;
+            } else {
+                v[1] = rp[x0];
             }
+            v[QUAD + 1] = x0 + QUAD < p.d[2] ? rp[x0 + QUAD] : 0.f;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int j = 0; j < QUAD; ++j) acc[ky * 3 + kx] += v[j + kx] * g[j];
         }
     }
     const int w = threadIdx.x >> 6;
@@ -334,35 +477,75 @@ int check_launch(const char* what) {
     return 0;
 }
 
+template <class K>
+int small_lds(K kern, size_t bytes) {
+    if (bytes > 160 * 1024) { mi_set_error("thin-channel kernel: LDS request exceeds 160 KiB"); return -1; }
+    if (bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)bytes);
+        if (e != hipSuccess) { mi_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return -2; }
+    }
+    return 0;
+}
+
+template <class TR, int KZ>
+int run_c1_fwd(const C1Params& p, hipStream_t st) {
+    constexpr int KK = KZ * 9, ROWS = 4;
+    const int ppb = 256 / (p.N / 8);
+    const size_t lds = (size_t)(p.N * KK + 2 * ppb * p.N) * sizeof(float);
+    if (int rc = small_lds(c1_s2_fwd_kernel<TR, KZ>, lds)) return rc;
+    dim3 grid((p.cd[2] + ppb - 1) / ppb, (p.cd[1] + ROWS - 1) / ROWS, p.nb * p.cd[0]);
+    hipLaunchKernelGGL((c1_s2_fwd_kernel<TR, KZ>), grid, dim3(256), lds, st, p);
+    return check_launch("c1_s2_fwd");
+}
+
+template <class TR, int KZ>
+int run_c1_T(const C1Params& p, hipStream_t st) {
+    constexpr int KK = KZ * 9;
+    constexpr int TZ = KZ == 3 ? 4 : 1, TY = 8, TX = KZ == 3 ? 8 : 32;
+    constexpr int NP = (KZ == 3 ? TZ + 1 : 1) * (TY + 1) * (TX + 1);
+    const size_t lds = (size_t)(KK * p.N + KK * NP) * sizeof(float);
+    if (int rc = small_lds(c1_s2_T_kernel<TR, KZ>, lds)) return rc;
+    dim3 grid((p.cd[2] + TX - 1) / TX, (p.cd[1] + TY - 1) / TY, p.nb * ((p.cd[0] + TZ - 1) / TZ));
+    hipLaunchKernelGGL((c1_s2_T_kernel<TR, KZ>), grid, dim3(256), lds, st, p);
+    return check_launch("c1_s2_T");
+}
+
 }  // namespace
 
 int launch_c1_s2_fwd(int dtype, const C1Params& p, hipStream_t st) {
     MI_CHECK(p.N % 8 == 0 && p.N >= 8 && p.N <= 256, "N must be a multiple of 8, at most 256");
-    const int KK = p.ndim == 3 ? 27 : 9;
-    const int cpix = p.cd[0] * p.cd[1] * p.cd[2];
-    const int ppb = 256 / (p.N / 8);
-    const size_t lds = (size_t)(p.N * KK + 2 * ppb * p.N) * sizeof(float);
-    dim3 grid((cpix + ppb - 1) / ppb, p.nb);
-    if (dtype) hipLaunchKernelGGL(c1_s2_fwd_kernel<BF16>, grid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL(c1_s2_fwd_kernel<F32>, grid, dim3(256), lds, st, p);
-    return check_launch("c1_s2_fwd");
+    MI_CHECK((long long)p.nb * p.cd[0] <= 65535, "batch x depth exceeds the grid limit");
+    if (p.ndim == 3) return dtype ? run_c1_fwd<BF16, 3>(p, st) : run_c1_fwd<F32, 3>(p, st);
+    return dtype ? run_c1_fwd<BF16, 1>(p, st) : run_c1_fwd<F32, 1>(p, st);
 }
 
 int launch_c1_s2_T(int dtype, const C1Params& p, hipStream_t st) {
     MI_CHECK(p.N % 8 == 0 && p.N >= 8 && p.N <= 256, "N must be a multiple of 8, at most 256");
-    const int KK = p.ndim == 3 ? 27 : 9;
-    const int fpix = p.fd[0] * p.fd[1] * p.fd[2];
-    const size_t lds = (size_t)p.N * KK * sizeof(float);
-    dim3 grid((fpix + 255) / 256, p.nb);
-    if (dtype) hipLaunchKernelGGL(c1_s2_T_kernel<BF16>, grid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL(c1_s2_T_kernel<F32>, grid, dim3(256), lds, st, p);
-    return check_launch("c1_s2_T");
+    MI_CHECK(p.fd[2] == 2 * p.cd[2] && p.fd[1] == 2 * p.cd[1] && (p.ndim == 2 || p.fd[0] == 2 * p.cd[0]),
+             "fine dims must be twice the coarse dims");
+    MI_CHECK((long long)p.nb * p.cd[0] <= 65535, "batch x depth exceeds the grid limit");
+    if (p.ndim == 3) return dtype ? run_c1_T<BF16, 3>(p, st) : run_c1_T<F32, 3>(p, st);
+    return dtype ? run_c1_T<BF16, 1>(p, st) : run_c1_T<F32, 1>(p, st);
+}
+
+// slabs (= workgroups along x) of the weight-gradient kernel: whole column blocks times row blocks
+int c1_wgrad_slabs(int N, const int cd[3]) {
+    const int ppb = 256 / (N / 8);
+    const int xblocks = (cd[2] + ppb - 1) / ppb;
+    int rb = 1024 / xblocks;
+    if (rb < 1) rb = 1;
+    return xblocks * rb;
 }
 
 // partial: [nsplit][KK][N] floats, partial_bias: [nsplit][N] floats
 int launch_c1_s2_wgrad(int dtype, const C1Params& p, hipStream_t st) {
     MI_CHECK(p.N % 8 == 0 && p.N >= 8 && p.N <= 512, "N must be a multiple of 8, at most 512");
+    MI_CHECK(p.n_y1 % 8 == 0 && p.n_y1 > 0 && (p.n_y1 >= p.N || p.y2 != nullptr), "second source missing or misaligned");
+    MI_CHECK(p.nsplit == c1_wgrad_slabs(p.N, p.cd), "nsplit must come from c1_wgrad_slabs()");
     const size_t lds = (size_t)4 * p.N * 10 * sizeof(float);
+    if (dtype) { if (int rc = small_lds(c1_s2_wgrad_kernel<BF16>, lds)) return rc; }
+    else { if (int rc = small_lds(c1_s2_wgrad_kernel<F32>, lds)) return rc; }
     dim3 grid(p.nsplit, p.ndim == 3 ? 3 : 1);
     if (dtype) hipLaunchKernelGGL(c1_s2_wgrad_kernel<BF16>, grid, dim3(256), lds, st, p);
     else hipLaunchKernelGGL(c1_s2_wgrad_kernel<F32>, grid, dim3(256), lds, st, p);
@@ -370,12 +553,20 @@ int launch_c1_s2_wgrad(int dtype, const C1Params& p, hipStream_t st) {
 }
 
 int launch_stencil(const StencilParams& p, hipStream_t st) {
-    const int npix = p.d[0] * p.d[1] * p.d[2];
-    hipLaunchKernelGGL(stencil_kernel, dim3((npix + 255) / 256, p.nb), dim3(256), 0, st, p);
+    const long long npix = (long long)p.d[0] * p.d[1] * p.d[2];
+    if (p.d[2] % 4 == 0) {
+        const unsigned gx = (unsigned)((npix / 4 + 255) / 256);
+        if (p.ndim == 3) hipLaunchKernelGGL(stencil_kernel<3>, dim3(gx, p.nb), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(stencil_kernel<1>, dim3(gx, p.nb), dim3(256), 0, st, p);
+    } else {
+        hipLaunchKernelGGL(stencil_scalar_kernel, dim3((unsigned)((npix + 255) / 256), p.nb), dim3(256), 0, st, p);
+    }
     return check_launch("stencil");
 }
 
 int launch_stencil_wgrad(const StencilParams& p, hipStream_t st) {
-    hipLaunchKernelGGL(stencil_wgrad_kernel, dim3(p.nsplit, p.ndim == 3 ? 3 : 1), dim3(256), 0, st, p);
+    dim3 grid(p.nsplit, p.ndim == 3 ? 3 : 1);
+    if (p.d[2] % 4 == 0) hipLaunchKernelGGL(stencil_wgrad_kernel<4>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(stencil_wgrad_kernel<1>, grid, dim3(256), 0, st, p);
     return check_launch("stencil_wgrad");
 }
