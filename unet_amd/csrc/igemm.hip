@@ -28,6 +28,9 @@ __device__ __forceinline__ v4f mma16<F32>(const uint4& a, const uint4& b, v4f c)
     return c;
 }
 
+// n / d for 0 <= n < 2^32 / d through the host-computed reciprocal mg = 2^32 / d + 1 (mg == 0: d == 1)
+__device__ __forceinline__ int fast_div(int n, unsigned mg) { return mg ? (int)__umulhi((unsigned)n, mg) : n; }
+
 // channel (within the workgroup's N tile) held by MFMA row `rr` of fragment `nf`
 template <int NFRAG>
 __device__ __forceinline__ int chan_of_row(int nf, int rr) {
@@ -90,32 +93,61 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
             const int ntg = min(p.tapg, t_end - tg);
             __syncthreads();
             if (tg == t_begin) {
-                // stage the input patch of this contraction chunk (zero outside the tensor)
-                for (int id = tid; id < PP * CPS; id += 256) {
-                    const int pix = id / CPS, cc = id % CPS;
-                    const int pz = pix / pd12; const int r = pix - pz * pd12;
-                    const int py = r / p.pd[2]; const int px = r - py * p.pd[2];
-                    const int iz = iz0 + pz, iy = iy0 + py, ix = ix0 + px;
-                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                    if ((unsigned)iz < (unsigned)p.id[0] && (unsigned)iy < (unsigned)p.id[1] &&
-                        (unsigned)ix < (unsigned)p.id[2]) {
-                        const size_t gp = ((size_t)(img * p.id[0] + iz) * p.id[1] + iy) * p.id[2] + ix;
-                        v = *reinterpret_cast<const uint4*>(src + (gp * spitch + scoff) * ESZ + cc * 16);
+                // stage the input patch of this contraction chunk (zero outside the tensor); loads are issued in
+                // batches of SU independent 16-byte vectors per thread before anything is written to LDS
+                constexpr int SU = 4;
+                const int total = PP * CPS;
+                for (int base = tid; base < total; base += 256 * SU) {
+                    uint4 v[SU];
+#pragma unroll
+                    for (int u = 0; u < SU; ++u) {
+                        const int id = base + u * 256;
+                        v[u] = make_uint4(0u, 0u, 0u, 0u);
+                        if (id < total) {
+                            const int pix = id / CPS, cc = id % CPS;
+                            const int pz = fast_div(pix, p.mg_pd12); const int r = pix - pz * pd12;
+                            const int py = fast_div(r, p.mg_pd2); const int px = r - py * p.pd[2];
+                            const int iz = iz0 + pz, iy = iy0 + py, ix = ix0 + px;
+                            if ((unsigned)iz < (unsigned)p.id[0] && (unsigned)iy < (unsigned)p.id[1] &&
+                                (unsigned)ix < (unsigned)p.id[2]) {
+                                const size_t gp = ((size_t)(img * p.id[0] + iz) * p.id[1] + iy) * p.id[2] + ix;
+                                v[u] = *reinterpret_cast<const uint4*>(src + (gp * spitch + scoff) * ESZ + cc * 16);
+                            }
+                        }
                     }
-                    *reinterpret_cast<uint4*>(smA + pix * PITCH + cc * 16) = v;
+#pragma unroll
+                    for (int u = 0; u < SU; ++u) {
+                        const int id = base + u * 256;
+                        if (id < total) *reinterpret_cast<uint4*>(smA + (id / CPS) * PITCH + (id % CPS) * 16) = v[u];
+                    }
                 }
             }
             // stage the weight tile: rows (tap, channel slot), this chunk's KCB bytes
             const int ntg_pad = (CPS == 2) ? ((ntg + 1) & ~1) : ntg;
-            for (int id = tid; id < ntg_pad * NT * CPS; id += 256) {
-                const int cc = id % CPS; const int row = id / CPS;
-                const int r = row % NT; const int tl = row / NT;
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (tl < ntg) {
-                    const int n = n0 + chan_of_row<NFRAG>(r >> 4, r & 15);
-                    v = *reinterpret_cast<const uint4*>(p.w + (((size_t)(tg + tl) * p.N + n) * p.K + kc) * ESZ + cc * 16);
+            {
+                constexpr int WU = 3;
+                const int wtotal = ntg_pad * NT * CPS;
+                for (int base = tid; base < wtotal; base += 256 * WU) {
+                    uint4 v[WU];
+#pragma unroll
+                    for (int u = 0; u < WU; ++u) {
+                        const int id = base + u * 256;
+                        v[u] = make_uint4(0u, 0u, 0u, 0u);
+                        if (id < wtotal) {
+                            const int cc = id % CPS; const int row = id / CPS;
+                            const int r = row % NT; const int tl = row / NT;
+                            if (tl < ntg) {
+                                const int n = n0 + chan_of_row<NFRAG>(r >> 4, r & 15);
+                                v[u] = *reinterpret_cast<const uint4*>(p.w + (((size_t)(tg + tl) * p.N + n) * p.K + kc) * ESZ + cc * 16);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < WU; ++u) {
+                        const int id = base + u * 256;
+                        if (id < wtotal) *reinterpret_cast<uint4*>(smW + (id / CPS) * PITCH + (id % CPS) * 16) = v[u];
+                    }
                 }
-                *reinterpret_cast<uint4*>(smW + row * PITCH + cc * 16) = v;
             }
             __syncthreads();
             const int nsteps = (CPS == 4) ? ntg : (ntg + 1) / 2;
@@ -292,36 +324,59 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
         const int iz0 = bz0 * p.ss + p.omin[0] + p.tg_zoff[tgi], iy0 = by0 * p.ss + p.omin[1],
                   ix0 = bx0 * p.ss + p.omin[2];
         __syncthreads();
-        // F tile: 256 base pixels x FB channels
+        // F tile: 256 base pixels x FB channels; S patch.  Loads go out in batches of independent 16-byte
+        // vectors per thread before the LDS writes.
         {
             constexpr int VPP = FB * ESZ / 16;  // 16-byte vectors per pixel
-            for (int id = tid; id < 256 * VPP; id += 256) {
-                const int pix = id / VPP, cv = id % VPP;
-                const int tx = pix & mx, ty = (pix >> p.tlog[2]) & my, tz = pix >> (p.tlog[2] + p.tlog[1]);
-                const int bz = bz0 + tz, by = by0 + ty, bx = bx0 + tx;
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (bz < p.bd[0] && by < p.bd[1] && bx < p.bd[2]) {
-                    const size_t gp = ((size_t)(img * p.bd[0] + bz) * p.bd[1] + by) * p.bd[2] + bx;
-                    v = *reinterpret_cast<const uint4*>(fsrc + (gp * fpitch + fcoff) * ESZ + cv * 16);
+            constexpr int FU = VPP < 8 ? VPP : 8;
+            for (int base = tid; base < 256 * VPP; base += 256 * FU) {
+                uint4 v[FU];
+#pragma unroll
+                for (int u = 0; u < FU; ++u) {
+                    const int id = base + u * 256;
+                    const int pix = id / VPP, cv = id % VPP;
+                    const int tx = pix & mx, ty = (pix >> p.tlog[2]) & my, tz = pix >> (p.tlog[2] + p.tlog[1]);
+                    const int bz = bz0 + tz, by = by0 + ty, bx = bx0 + tx;
+                    v[u] = make_uint4(0u, 0u, 0u, 0u);
+                    if (bz < p.bd[0] && by < p.bd[1] && bx < p.bd[2]) {
+                        const size_t gp = ((size_t)(img * p.bd[0] + bz) * p.bd[1] + by) * p.bd[2] + bx;
+                        v[u] = *reinterpret_cast<const uint4*>(fsrc + (gp * fpitch + fcoff) * ESZ + cv * 16);
+                    }
                 }
-                *reinterpret_cast<uint4*>(smF + pix * FPITCH + cv * 16) = v;
+#pragma unroll
+                for (int u = 0; u < FU; ++u) {
+                    const int id = base + u * 256;
+                    *reinterpret_cast<uint4*>(smF + (id / VPP) * FPITCH + (id % VPP) * 16) = v[u];
+                }
             }
         }
-        // S patch
         {
             constexpr int VPP = SB * ESZ / 16;
-            for (int id = tid; id < PP * VPP; id += 256) {
-                const int pix = id / VPP, cv = id % VPP;
-                const int pz = pix / pd12; const int r = pix - pz * pd12;
-                const int py = r / p.pd[2]; const int px = r - py * p.pd[2];
-                const int iz = iz0 + pz, iy = iy0 + py, ix = ix0 + px;
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if ((unsigned)iz < (unsigned)p.sd[0] && (unsigned)iy < (unsigned)p.sd[1] &&
-                    (unsigned)ix < (unsigned)p.sd[2]) {
-                    const size_t gp = ((size_t)(img * p.sd[0] + iz) * p.sd[1] + iy) * p.sd[2] + ix;
-                    v = *reinterpret_cast<const uint4*>(p.s + (gp * p.s_pitch + p.s_coff + sb0) * ESZ + cv * 16);
+            constexpr int SU = 4;
+            const int total = PP * VPP;
+            for (int base = tid; base < total; base += 256 * SU) {
+                uint4 v[SU];
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const int id = base + u * 256;
+                    v[u] = make_uint4(0u, 0u, 0u, 0u);
+                    if (id < total) {
+                        const int pix = id / VPP, cv = id % VPP;
+                        const int pz = fast_div(pix, p.mg_pd12); const int r = pix - pz * pd12;
+                        const int py = fast_div(r, p.mg_pd2); const int px = r - py * p.pd[2];
+                        const int iz = iz0 + pz, iy = iy0 + py, ix = ix0 + px;
+                        if ((unsigned)iz < (unsigned)p.sd[0] && (unsigned)iy < (unsigned)p.sd[1] &&
+                            (unsigned)ix < (unsigned)p.sd[2]) {
+                            const size_t gp = ((size_t)(img * p.sd[0] + iz) * p.sd[1] + iy) * p.sd[2] + ix;
+                            v[u] = *reinterpret_cast<const uint4*>(p.s + (gp * p.s_pitch + p.s_coff + sb0) * ESZ + cv * 16);
+                        }
+                    }
                 }
-                *reinterpret_cast<uint4*>(smS + pix * SPITCH + cv * 16) = v;
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const int id = base + u * 256;
+                    if (id < total) *reinterpret_cast<uint4*>(smS + (id / VPP) * SPITCH + (id % VPP) * 16) = v[u];
+                }
             }
         }
         __syncthreads();
@@ -572,8 +627,12 @@ int set_lds(K kern, size_t bytes) {
     return 0;
 }
 
+unsigned magic_of(int d) { return d <= 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)d) + 1u; }
+
 template <class TR, int CPS, int NFRAG>
-int launch_igemm_t(const IgemmParams& p, hipStream_t st) {
+int launch_igemm_t(const IgemmParams& pin, hipStream_t st) {
+    IgemmParams p = pin;
+    p.mg_pd2 = magic_of(p.pd[2]); p.mg_pd12 = magic_of(p.pd[1] * p.pd[2]);
     constexpr int PITCH = CPS * 16 + 16;
     const int PP = p.pd[0] * p.pd[1] * p.pd[2];
     const int tapg_pad = (CPS == 2) ? ((p.tapg + 1) & ~1) : p.tapg;
@@ -589,7 +648,9 @@ int launch_igemm_t(const IgemmParams& p, hipStream_t st) {
 }
 
 template <class TR, int NT, int FF, int SF, int WF, int WS>
-int launch_wgrad_t(const WgradParams& p, hipStream_t st) {
+int launch_wgrad_t(const WgradParams& pin, hipStream_t st) {
+    WgradParams p = pin;
+    p.mg_pd2 = magic_of(p.pd[2]); p.mg_pd12 = magic_of(p.pd[1] * p.pd[2]);
     constexpr int FB = 16 * FF * WF, SB = 16 * SF * WS;
     constexpr int FPITCH = FB * TR::ESZ + 16, SPITCH = SB * TR::ESZ + 16;
     const int PP = p.pd[0] * p.pd[1] * p.pd[2];

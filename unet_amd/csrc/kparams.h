@@ -33,6 +33,7 @@ struct IgemmParams {
     int phase_start[MI_MAX_PHASE + 1];      // tap range of each phase in tap_off / w
     int tap_off[MI_MAX_TAPS];               // LDS patch pixel offset of each tap
     int tapg;                               // taps staged per weight tile (<= 9)
+    unsigned mg_pd2, mg_pd12;               // reciprocals of pd[2] and pd[1]*pd[2], filled in by the launcher
 };
 
 // Weight-gradient launch: partial[slab][tap][f][s] = sum_{base pixels of the slab}
@@ -51,6 +52,7 @@ struct WgradParams {
     int ntaps_total;
     float* partial; float* partial_bias;
     int tiles_total, nsplit;
+    unsigned mg_pd2, mg_pd12;               // reciprocals of pd[2] and pd[1]*pd[2], filled in by the launcher
 };
 
 // Reduction of weight-gradient slabs into the state_dict layout:
