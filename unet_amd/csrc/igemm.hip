@@ -273,6 +273,247 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------
+// forward / dgrad, two-dimensional unit-stride specialisation
+// ---------------------------------------------------------------------------------
+// sum over the 16 lanes of a DPP row (lanes that share lane >> 4); lane 0 of the row adds in a fixed order
+__device__ __forceinline__ float row_sum16(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));  // row_mirror
+    return v;
+}
+
+// Same contract as igemm_kernel for 2-D tensors gathered with unit stride (sa = 1) and a 16 x 16 tile.
+// KS = 3: 3x3 taps (patch 18 x 18), KS = 1: one tap (16 x 16), KS = 2: the stride-2 scatter phases whose
+// taps sit at offsets {0,1}^2 (17 x 17).  With the geometry known at compile time the per-lane state is
+// one LDS base and one output offset; a workgroup walks `tpw` consecutive tiles of one image row, keeps
+// its staging descriptors in registers, stages the weight image once when a single staging covers it
+// and reduces the statistics partials once.
+template <class TR, int CPS, int NFRAG, int KS>
+__global__ __launch_bounds__(256) void igemm2d_kernel(const IgemmParams p) {
+    constexpr int ESZ = TR::ESZ;
+    constexpr int KCB = CPS * 16, KCE = KCB / ESZ, PITCH = KCB + 16, NT = NFRAG * 16;
+    constexpr int PD = KS == 3 ? 18 : KS == 2 ? 17 : 16;
+    constexpr int PP = PD * PD, TOTAL = PP * CPS, NSLOT = (TOTAL + 255) / 256;
+    constexpr int MAXTAP = KS == 3 ? 9 : KS == 2 ? 4 : 1;
+    constexpr int TAPPAD = (CPS == 2) ? ((MAXTAP + 1) & ~1) : MAXTAP;
+    constexpr int MAXW = (TAPPAD * NT * CPS + 255) / 256;
+    constexpr int RSTEP = (256 / CPS) * PITCH;     // LDS bytes between two staging slots of a thread
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* smA = smem;
+    char* smW = smem + PP * PITCH;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, g = lane >> 4;
+    const int ntx = p.ntile[2];
+    const int wg_per_row = ntx / p.tpw;
+    int b = blockIdx.x;
+    const int txw = b % wg_per_row; b /= wg_per_row;
+    const int tyi = b % p.ntile[1];
+    const int img = b / p.ntile[1];
+    const int slot = blockIdx.x % MI_NSLOT;
+    const int n0 = blockIdx.y * NT;
+    const int ph = blockIdx.z;
+    const int H = p.id[1], W = p.id[2];
+    const int t_begin = p.phase_start[ph], ntap = p.phase_start[ph + 1] - t_begin;
+    const bool w_once = p.K <= KCE;
+
+    // lane constants: tile pixel (ty = 4 wave + mf, tx = lr)
+    const int a_base0 = ((wave * 4) * PD + lr) * PITCH;
+    const int rel0 = (wave * 4 * p.so) * p.od[2] + lr * p.so;
+    const int rel_step = p.so * p.od[2];
+    const int cc_s = tid % CPS;
+    const int lo0 = (tid / CPS) * PITCH + cc_s * 16;
+    int s_pl[NSLOT], s_co[NSLOT];
+#pragma unroll
+    for (int u = 0; u < NSLOT; ++u) {
+        const int pix = tid / CPS + u * (256 / CPS);
+        const int py = pix / PD, px = pix - py * PD;
+        s_pl[u] = py * W + px;
+        s_co[u] = (u * 256 + tid < TOTAL) ? ((py << 10) | px) : -1;
+    }
+    unsigned w_d[MAXW];
+#pragma unroll
+    for (int u = 0; u < MAXW; ++u) {
+        const int row = tid / CPS + u * (256 / CPS);
+        const int r = row % NT, tl = row / NT;
+        const int n = n0 + chan_of_row<NFRAG>(r >> 4, r & 15);
+        w_d[u] = ((unsigned)tl << 27) | (unsigned)(((tl * p.N + n) * p.K) * ESZ + cc_s * 16);
+    }
+    const int ntap_pad = (CPS == 2) ? ((ntap + 1) & ~1) : ntap;
+    auto stage_weights = [&](int kc) {
+        const char* wb = p.w + ((size_t)t_begin * p.N * p.K + kc) * ESZ;
+        uint4 v[MAXW];
+#pragma unroll
+        for (int u = 0; u < MAXW; ++u) {
+            v[u] = make_uint4(0u, 0u, 0u, 0u);
+            if ((int)(w_d[u] >> 27) < ntap) v[u] = *reinterpret_cast<const uint4*>(wb + (w_d[u] & 0x7ffffffu));
+        }
+#pragma unroll
+        for (int u = 0; u < MAXW; ++u)
+            if ((int)(w_d[u] >> 27) < ntap_pad) *reinterpret_cast<uint4*>(smW + lo0 + u * RSTEP) = v[u];
+    };
+    if (w_once) stage_weights(0);
+    int toffs[MAXTAP];
+#pragma unroll
+    for (int t = 0; t < MAXTAP; ++t) toffs[t] = p.tap_off[t_begin + (t < ntap ? t : 0)] * PITCH;
+
+    const bool do_stats = p.stats != nullptr;
+    float s1[NFRAG][4], s2[NFRAG][4];
+#pragma unroll
+    for (int nf = 0; nf < NFRAG; ++nf)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s1[nf][j] = 0.f; s2[nf][j] = 0.f; }
+
+    const int by0 = tyi << 4;
+    const int iy0 = by0 + p.omin[1];
+    for (int ti = 0; ti < p.tpw; ++ti) {
+        const int bx0 = (txw * p.tpw + ti) << 4;
+        const int ix0 = bx0 + p.omin[2];
+        const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + PD <= H && ix0 + PD <= W;
+        const long long org = ((long long)img * H + iy0) * W + ix0;   // patch origin pixel (may lie outside)
+
+        v4f acc[4][NFRAG];
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < NFRAG; ++nf) acc[mf][nf] = v4f{0.f, 0.f, 0.f, 0.f};
+
+        for (int kc = 0; kc < p.K; kc += KCE) {
+            const char* src;
+            int spitch, scoff;
+            if (kc < p.in0_c) { src = p.in0; spitch = p.in0_pitch; scoff = p.in0_coff + kc; }
+            else { src = p.in1; spitch = p.in1_pitch; scoff = p.in1_coff + kc - p.in0_c; }
+            const int spb = spitch * ESZ;
+            const char* pb = src + org * spb + scoff * ESZ + cc_s * 16;   // only dereferenced inside the tensor
+            __syncthreads();
+            {
+                uint4 v[NSLOT];
+#pragma unroll
+                for (int u = 0; u < NSLOT; ++u) {
+                    v[u] = make_uint4(0u, 0u, 0u, 0u);
+                    bool ok = s_co[u] >= 0;
+                    if (!interior && ok) {
+                        const int iy = iy0 + (s_co[u] >> 10), ix = ix0 + (s_co[u] & 1023);
+                        ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                    }
+                    if (ok) v[u] = *reinterpret_cast<const uint4*>(pb + (size_t)__umul24(s_pl[u], spb));
+                }
+#pragma unroll
+                for (int u = 0; u < NSLOT; ++u)
+                    if (s_co[u] >= 0) *reinterpret_cast<uint4*>(smA + lo0 + u * RSTEP) = v[u];
+            }
+            if (!w_once) stage_weights(kc);
+            __syncthreads();
+            constexpr int NSTEP = (CPS == 4) ? MAXTAP : (MAXTAP + 1) / 2;
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) {
+                int tl, cc, toff;
+                if (CPS == 4) {
+                    if (s >= ntap) break;
+                    tl = s; cc = g; toff = toffs[s];
+                } else {
+                    if (2 * s >= ntap) break;
+                    tl = 2 * s + (g >> 1); cc = g & 1;
+                    toff = (g >> 1) ? toffs[(2 * s + 1 < MAXTAP) ? 2 * s + 1 : 2 * s] : toffs[2 * s];
+                }
+                uint4 bfr[4], afr[NFRAG];
+#pragma unroll
+                for (int mf = 0; mf < 4; ++mf)
+                    bfr[mf] = *reinterpret_cast<const uint4*>(smA + a_base0 + mf * PD * PITCH + toff + cc * 16);
+#pragma unroll
+                for (int nf = 0; nf < NFRAG; ++nf)
+                    afr[nf] = *reinterpret_cast<const uint4*>(smW + ((tl * NT + nf * 16 + lr) * PITCH) + cc * 16);
+#pragma unroll
+                for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+                    for (int nf = 0; nf < NFRAG; ++nf) acc[mf][nf] = mma16<TR>(afr[nf], bfr[mf], acc[mf][nf]);
+            }
+        }
+
+        // ---- tile epilogue ---------------------------------------------------------------------
+        const bool full = by0 + 16 <= p.bd[1] && bx0 + 16 <= p.bd[2];
+        const int base_pix = (img * p.od[1] + by0 * p.so + p.phase_off[ph][1]) * p.od[2] + bx0 * p.so + p.phase_off[ph][2];
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) {
+            const bool valid = full || (by0 + wave * 4 + mf < p.bd[1] && bx0 + lr < p.bd[2]);
+            if (do_stats) {
+#pragma unroll
+                for (int nf = 0; nf < NFRAG; ++nf)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float v = valid ? acc[mf][nf][j] : 0.f;
+                        s1[nf][j] += v; s2[nf][j] += v * v;
+                    }
+            }
+            if (valid) {
+                const size_t op = (size_t)(base_pix + rel0 + mf * rel_step);
+                if (NFRAG == 1) {
+                    const int ch = n0 + 4 * g;
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = acc[mf][0][j];
+                    if (p.bias && ch >= p.bias_c0) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += p.bias[ch - p.bias_c0 + j];
+                    }
+                    if (p.addend) {
+                        float a[4];
+                        load_n<TR, 4>(p.addend + (op * p.add_pitch + p.add_coff + ch) * ESZ, a);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += a[j];
+                    }
+                    store_n<TR, 4>(p.out + (op * p.out_pitch + p.out_coff + ch) * ESZ, v);
+                } else {
+#pragma unroll
+                    for (int pf = 0; pf < NFRAG / 2; ++pf) {
+                        const int ch = n0 + 32 * pf + 8 * g;
+                        float v[8];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { v[j] = acc[mf][2 * pf][j]; v[4 + j] = acc[mf][2 * pf + 1][j]; }
+                        if (p.bias && ch >= p.bias_c0) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] += p.bias[ch - p.bias_c0 + j];
+                        }
+                        if (p.addend) {
+                            float a[8];
+                            load_n<TR, 8>(p.addend + (op * p.add_pitch + p.add_coff + ch) * ESZ, a);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] += a[j];
+                        }
+                        store_n<TR, 8>(p.out + (op * p.out_pitch + p.out_coff + ch) * ESZ, v);
+                    }
+                }
+            }
+        }
+    }
+    if (do_stats) {
+        __syncthreads();
+        float* sst = reinterpret_cast<float*>(smem);  // [4 waves][NT][2]
+#pragma unroll
+        for (int nf = 0; nf < NFRAG; ++nf)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = row_sum16(s1[nf][j]), bsum = row_sum16(s2[nf][j]);
+                if (lr == 0) {
+                    const int cl = chan_of_row<NFRAG>(nf, 4 * g + j);
+                    sst[(wave * NT + cl) * 2] = a;
+                    sst[(wave * NT + cl) * 2 + 1] = bsum;
+                }
+            }
+        __syncthreads();
+        for (int i = tid; i < NT * 2; i += 256) {
+            const int ch = n0 + (i >> 1);
+            if (ch < p.nstat) {
+                const float v = ((sst[i] + sst[NT * 2 + i]) + sst[2 * NT * 2 + i]) + sst[3 * NT * 2 + i];
+                atomicAdd(&p.stats[(((size_t)img * MI_NSLOT + slot) * p.stats_c + ch) * 2 + (i & 1)], (double)v);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // weight gradient
 // ---------------------------------------------------------------------------------
 // Workgroup = 4 waves arranged WK x WF x WS: WF x WS waves tile the (F, S) channel block,
@@ -647,6 +888,43 @@ int launch_igemm_t(const IgemmParams& pin, hipStream_t st) {
     return 0;
 }
 
+// 2-D unit-stride specialisation: usable when the generic geometry chose a 16 x 16 tile on a 2-D tensor
+inline int igemm2d_ks(const IgemmParams& p) {
+    if (p.sa != 1 || p.id[0] != 1 || p.tlog[0] != 0 || p.tlog[1] != 4 || p.tlog[2] != 4 || p.pd[0] != 1) return 0;
+    const int ntaps = p.phase_start[p.nphase];
+    if (p.nphase == 4 && p.so == 2 && p.pd[1] == 17 && p.pd[2] == 17 && ntaps == 9) return 2;
+    if (p.nphase == 1 && p.so == 1 && ntaps == 9 && p.pd[1] == 18 && p.pd[2] == 18) return 3;
+    if (p.nphase == 1 && p.so == 1 && ntaps == 1 && p.pd[1] == 16 && p.pd[2] == 16) return 1;
+    return 0;
+}
+
+template <class TR, int CPS, int NFRAG, int KS>
+int launch_igemm2d_t(const IgemmParams& pin, hipStream_t st) {
+    IgemmParams p = pin;
+    constexpr int PITCH = CPS * 16 + 16, NT = NFRAG * 16;
+    constexpr int PD = KS == 3 ? 18 : KS == 2 ? 17 : 16;
+    constexpr int MAXTAP = KS == 3 ? 9 : KS == 2 ? 4 : 1;
+    constexpr int TAPPAD = (CPS == 2) ? ((MAXTAP + 1) & ~1) : MAXTAP;
+    {
+        // tiles per workgroup (consecutive along x): about eight workgroups per CU stay in flight
+        const long long wgs = (long long)p.nb * p.ntile[1] * p.ntile[2] * (p.N / NT) * p.nphase;
+        int want = (int)(wgs / 2048);
+        if (want > 8) want = 8;
+        int tpw = 1;
+        for (int t = 1; t <= want; ++t) if (p.ntile[2] % t == 0) tpw = t;
+        p.tpw = tpw;
+    }
+    size_t lds = (size_t)PD * PD * PITCH + (size_t)TAPPAD * NT * PITCH;
+    if (lds < (size_t)NT * 2 * 4 * 4) lds = NT * 2 * 4 * 4;
+    auto kern = igemm2d_kernel<TR, CPS, NFRAG, KS>;
+    if (int r = set_lds(kern, lds)) return r;
+    dim3 grid(p.nb * p.ntile[1] * (p.ntile[2] / p.tpw), p.N / NT, p.nphase);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { mi_set_error(std::string("igemm2d launch: ") + hipGetErrorString(e)); return -2; }
+    return 0;
+}
+
 template <class TR, int NT, int FF, int SF, int WF, int WS>
 int launch_wgrad_t(const WgradParams& pin, hipStream_t st) {
     WgradParams p = pin;
@@ -708,8 +986,16 @@ int launch_igemm(int dtype, const IgemmParams& p, hipStream_t st) {
     MI_CHECK(p.tlog[0] + p.tlog[1] + p.tlog[2] == 8, "tile must hold 256 base pixels");
     MI_CHECK(p.tapg >= 1 && p.tapg <= 9, "tap group size");
     MI_CHECK(igemm_lds_for(p, cps, nfrag) <= 160 * 1024, "LDS images do not fit");
-#define IG_CASE(TRT, C, NF) \
-    if (cps == C && nfrag == NF) return launch_igemm_t<TRT, C, NF>(p, st);
+    MI_CHECK((long long)p.nb * p.od[0] * p.od[1] * p.od[2] < (1ll << 31) && (long long)p.nb * p.id[0] * p.id[1] * p.id[2] < (1ll << 31),
+             "tensor has too many pixels for 32-bit pixel indices");
+    const int ks = getenv("MI_NO_IGEMM2D") ? 0 : igemm2d_ks(p);
+#define IG_CASE(TRT, C, NF)                                                  \
+    if (cps == C && nfrag == NF) {                                           \
+        if (ks == 3) return launch_igemm2d_t<TRT, C, NF, 3>(p, st);          \
+        if (ks == 2) return launch_igemm2d_t<TRT, C, NF, 2>(p, st);          \
+        if (ks == 1) return launch_igemm2d_t<TRT, C, NF, 1>(p, st);          \
+        return launch_igemm_t<TRT, C, NF>(p, st);                            \
+    }
     if (dtype) {
         IG_CASE(BF16, 4, 4) IG_CASE(BF16, 4, 2) IG_CASE(BF16, 4, 1)
         IG_CASE(BF16, 2, 4) IG_CASE(BF16, 2, 2) IG_CASE(BF16, 2, 1)

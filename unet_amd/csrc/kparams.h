@@ -34,6 +34,7 @@ struct IgemmParams {
     int tap_off[MI_MAX_TAPS];               // LDS patch pixel offset of each tap
     int tapg;                               // taps staged per weight tile (<= 9)
     unsigned mg_pd2, mg_pd12;               // reciprocals of pd[2] and pd[1]*pd[2], filled in by the launcher
+    int tpw;                                // 2-D specialisation: consecutive tiles per workgroup, filled in by the launcher
 };
 
 // Weight-gradient launch: partial[slab][tap][f][s] = sum_{base pixels of the slab}

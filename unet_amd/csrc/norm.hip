@@ -28,7 +28,28 @@ __device__ __forceinline__ void load_moments(const double* stats, int img, int c
     }
 }
 
-constexpr int NORM_ITEMS = 8;  // vectors per thread per block
+constexpr int NORM_U = 4;      // independent 16-byte loads in flight per thread and tensor
+
+// Thread layout shared by the three kernels: cv_n = 16-byte vectors per pixel, a sweep of the workgroup
+// covers rows = 256 / cv_n pixels, thread (prow, cv) keeps the same channel group for all its pixels, so
+// the moments of its channels live in registers.  Workgroup b handles pixels [b*ppb, (b+1)*ppb).
+struct NormLane {
+    int cv, prow, rows, ch0, pbeg, pend;
+    bool active;
+};
+template <int VEC>
+__device__ __forceinline__ NormLane norm_lane(const NormParams& p) {
+    NormLane l;
+    const int cv_n = p.c / VEC;
+    l.rows = 256 / cv_n;
+    l.cv = threadIdx.x % cv_n; l.prow = threadIdx.x / cv_n;
+    l.ch0 = l.cv * VEC;
+    const int ppb = (p.npix + gridDim.x - 1) / gridDim.x;
+    l.pbeg = blockIdx.x * ppb;
+    l.pend = min(p.npix, l.pbeg + ppb);
+    l.active = l.prow < l.rows;
+    return l;
+}
 
 template <class TR>
 __global__ __launch_bounds__(256) void norm_fwd_kernel(const NormParams p) {
@@ -37,32 +58,46 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const NormParams p) {
     const int img = blockIdx.y;
     load_moments(p.stats, img, p.c, p.npix, p.eps, sm);
     __syncthreads();
+    const NormLane l = norm_lane<VEC>(p);
+    if (!l.active) return;
     const float alpha = *p.alpha;
-    const int cv_n = p.c / VEC;
-    const long long nvec = (long long)p.npix * cv_n;
-    const long long v0 = (long long)blockIdx.x * 256 * NORM_ITEMS;
+    float mean[VEC], rstd[VEC];
 #pragma unroll
-    for (int it = 0; it < NORM_ITEMS; ++it) {
-        const long long v = v0 + it * 256 + threadIdx.x;
-        if (v >= nvec) break;
-        const int pix = (int)(v / cv_n), cv = (int)(v - (long long)pix * cv_n);
-        const size_t gp = (size_t)img * p.npix + pix;
-        const int ch0 = cv * VEC;
-        float x[VEC], r[VEC], o[VEC];
-        load_vec<TR>(p.x + (gp * p.x_pitch + p.x_coff + ch0) * ESZ, x);
-        if (p.res) load_vec<TR>(p.res + (gp * p.res_pitch + p.res_coff + ch0) * ESZ, r);
+    for (int e = 0; e < VEC; ++e) { mean[e] = sm[(l.ch0 + e) * 2]; rstd[e] = sm[(l.ch0 + e) * 2 + 1]; }
+    const size_t img_pix = (size_t)img * p.npix;
+    const char* xb = p.x + (img_pix * p.x_pitch + p.x_coff + l.ch0) * ESZ;
+    const char* rb = p.res ? p.res + (img_pix * p.res_pitch + p.res_coff + l.ch0) * ESZ : nullptr;
+    char* ob = p.out + (img_pix * p.out_pitch + p.out_coff + l.ch0) * ESZ;
+    const size_t xs = (size_t)p.x_pitch * ESZ, rs = (size_t)p.res_pitch * ESZ, os = (size_t)p.out_pitch * ESZ;
+    for (int pix0 = l.pbeg + l.prow; pix0 < l.pend; pix0 += l.rows * NORM_U) {
+        float x[NORM_U][VEC], r[NORM_U][VEC];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            float d = (x[e] - sm[(ch0 + e) * 2]) * sm[(ch0 + e) * 2 + 1];
-            if (p.drop_thresh) {
-                const bool keep = dropout_keep(p.seed, p.layer, (unsigned long long)gp * p.c + ch0 + e, p.drop_thresh);
-                d = keep ? d * p.drop_scale : 0.f;
+        for (int u = 0; u < NORM_U; ++u) {
+            const int pix = pix0 + u * l.rows;
+            if (pix < l.pend) {
+                load_vec<TR>(xb + pix * xs, x[u]);
+                if (rb) load_vec<TR>(rb + pix * rs, r[u]);
             }
-            float y = d > 0.f ? d : alpha * d;
-            if (p.res) y += r[e];
-            o[e] = y;
         }
-        store_vec<TR>(p.out + (gp * p.out_pitch + p.out_coff + ch0) * ESZ, o);
+#pragma unroll
+        for (int u = 0; u < NORM_U; ++u) {
+            const int pix = pix0 + u * l.rows;
+            if (pix < l.pend) {
+                float o[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    float d = (x[u][e] - mean[e]) * rstd[e];
+                    if (p.drop_thresh) {
+                        const bool keep = dropout_keep(p.seed, p.layer, (unsigned long long)(img_pix + pix) * p.c + l.ch0 + e, p.drop_thresh);
+                        d = keep ? d * p.drop_scale : 0.f;
+                    }
+                    float y = d > 0.f ? d : alpha * d;
+                    if (rb) y += r[u][e];
+                    o[e] = y;
+                }
+                store_vec<TR>(ob + pix * os, o);
+            }
+        }
     }
 }
 
@@ -78,37 +113,50 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const NormParams p
     float* part = sm + 2 * p.c;
     load_moments(p.stats, img, p.c, p.npix, p.eps, sm);
     __syncthreads();
-    const float alpha = *p.alpha;
+    const NormLane l = norm_lane<VEC>(p);
     const int cv_n = p.c / VEC;
-    const int rows = 256 / cv_n;   // pixel rows handled per sweep (cv_n <= 256 is checked by the launcher)
-    const int cv = threadIdx.x % cv_n, prow = threadIdx.x / cv_n;
-    const int ch0 = cv * VEC;
-    const int pix_per_block = (p.npix + gridDim.x - 1) / gridDim.x;
-    const int pbeg = blockIdx.x * pix_per_block;
-    const int pend = min(p.npix, pbeg + pix_per_block);
+    const float alpha = *p.alpha;
     float s1[VEC], s2[VEC], da = 0.f;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
-    if (prow < rows) {
-        for (int pix = pbeg + prow; pix < pend; pix += rows) {
-            const size_t gp = (size_t)img * p.npix + pix;
-            float x[VEC], dy[VEC];
-            load_vec<TR>(p.x + (gp * p.x_pitch + p.x_coff + ch0) * ESZ, x);
-            load_vec<TR>(p.dy + (gp * p.dy_pitch + p.dy_coff + ch0) * ESZ, dy);
+    if (l.active) {
+        float mean[VEC], rstd[VEC];
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const float xh = (x[e] - sm[(ch0 + e) * 2]) * sm[(ch0 + e) * 2 + 1];
-                float d = xh, sc = 1.f;
-                if (p.drop_thresh) {
-                    const bool keep =
-                        dropout_keep(p.seed, p.layer, (unsigned long long)gp * p.c + ch0 + e, p.drop_thresh);
-                    sc = keep ? p.drop_scale : 0.f;
-                    d = xh * sc;
+        for (int e = 0; e < VEC; ++e) { mean[e] = sm[(l.ch0 + e) * 2]; rstd[e] = sm[(l.ch0 + e) * 2 + 1]; }
+        const size_t img_pix = (size_t)img * p.npix;
+        const char* xb = p.x + (img_pix * p.x_pitch + p.x_coff + l.ch0) * ESZ;
+        const char* gb = p.dy + (img_pix * p.dy_pitch + p.dy_coff + l.ch0) * ESZ;
+        const size_t xs = (size_t)p.x_pitch * ESZ, gs = (size_t)p.dy_pitch * ESZ;
+        for (int pix0 = l.pbeg + l.prow; pix0 < l.pend; pix0 += l.rows * NORM_U) {
+            float x[NORM_U][VEC], dy[NORM_U][VEC];
+#pragma unroll
+            for (int u = 0; u < NORM_U; ++u) {
+                const int pix = pix0 + u * l.rows;
+                if (pix < l.pend) {
+                    load_vec<TR>(xb + pix * xs, x[u]);
+                    load_vec<TR>(gb + pix * gs, dy[u]);
                 }
-                const float gd = dy[e] * (d > 0.f ? 1.f : alpha);
-                da += dy[e] * fminf(d, 0.f);
-                const float gh = gd * sc;
-                s1[e] += gh; s2[e] += gh * xh;
+            }
+#pragma unroll
+            for (int u = 0; u < NORM_U; ++u) {
+                const int pix = pix0 + u * l.rows;
+                if (pix < l.pend) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const float xh = (x[u][e] - mean[e]) * rstd[e];
+                        float d = xh, sc = 1.f;
+                        if (p.drop_thresh) {
+                            const bool keep = dropout_keep(p.seed, p.layer, (unsigned long long)(img_pix + pix) * p.c + l.ch0 + e,
+                                                           p.drop_thresh);
+                            sc = keep ? p.drop_scale : 0.f;
+                            d = xh * sc;
+                        }
+                        const float gd = dy[u][e] * (d > 0.f ? 1.f : alpha);
+                        da += dy[u][e] * fminf(d, 0.f);
+                        const float gh = gd * sc;
+                        s1[e] += gh; s2[e] += gh * xh;
+                    }
+                }
             }
         }
     }
@@ -125,7 +173,7 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const NormParams p
         const int ch = i >> 1, k = i & 1;
         const int ccv = ch / VEC, e = ch - ccv * VEC;
         float a = 0.f;
-        for (int r = 0; r < rows; ++r) a += part[(r * cv_n + ccv) * 2 * VEC + k * VEC + e];
+        for (int r = 0; r < l.rows; ++r) a += part[(r * cv_n + ccv) * 2 * VEC + k * VEC + e];
         atomicAdd(&p.bstats[(((size_t)img * MI_NSLOT + slot) * p.c) * 2 + i], (double)a);
     }
     if (threadIdx.x == 0 && p.dalpha) {
@@ -150,34 +198,50 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const NormParams p)
         bm[i] = (float)(a / (double)p.npix);
     }
     __syncthreads();
+    const NormLane l = norm_lane<VEC>(p);
+    if (!l.active) return;
     const float alpha = *p.alpha;
-    const int cv_n = p.c / VEC;
-    const long long nvec = (long long)p.npix * cv_n;
-    const long long v0 = (long long)blockIdx.x * 256 * NORM_ITEMS;
+    float mean[VEC], rstd[VEC], b1[VEC], b2[VEC];
 #pragma unroll
-    for (int it = 0; it < NORM_ITEMS; ++it) {
-        const long long v = v0 + it * 256 + threadIdx.x;
-        if (v >= nvec) break;
-        const int pix = (int)(v / cv_n), cv = (int)(v - (long long)pix * cv_n);
-        const size_t gp = (size_t)img * p.npix + pix;
-        const int ch0 = cv * VEC;
-        float x[VEC], dy[VEC], o[VEC];
-        load_vec<TR>(p.x + (gp * p.x_pitch + p.x_coff + ch0) * ESZ, x);
-        load_vec<TR>(p.dy + (gp * p.dy_pitch + p.dy_coff + ch0) * ESZ, dy);
+    for (int e = 0; e < VEC; ++e) {
+        mean[e] = sm[(l.ch0 + e) * 2]; rstd[e] = sm[(l.ch0 + e) * 2 + 1];
+        b1[e] = bm[(l.ch0 + e) * 2]; b2[e] = bm[(l.ch0 + e) * 2 + 1];
+    }
+    const size_t img_pix = (size_t)img * p.npix;
+    const char* xb = p.x + (img_pix * p.x_pitch + p.x_coff + l.ch0) * ESZ;
+    const char* gb = p.dy + (img_pix * p.dy_pitch + p.dy_coff + l.ch0) * ESZ;
+    char* ob = p.out + (img_pix * p.out_pitch + p.out_coff + l.ch0) * ESZ;
+    const size_t xs = (size_t)p.x_pitch * ESZ, gs = (size_t)p.dy_pitch * ESZ, os = (size_t)p.out_pitch * ESZ;
+    for (int pix0 = l.pbeg + l.prow; pix0 < l.pend; pix0 += l.rows * NORM_U) {
+        float x[NORM_U][VEC], dy[NORM_U][VEC];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            const float rstd = sm[(ch0 + e) * 2 + 1];
-            const float xh = (x[e] - sm[(ch0 + e) * 2]) * rstd;
-            float d = xh, sc = 1.f;
-            if (p.drop_thresh) {
-                const bool keep = dropout_keep(p.seed, p.layer, (unsigned long long)gp * p.c + ch0 + e, p.drop_thresh);
-                sc = keep ? p.drop_scale : 0.f;
-                d = xh * sc;
+        for (int u = 0; u < NORM_U; ++u) {
+            const int pix = pix0 + u * l.rows;
+            if (pix < l.pend) {
+                load_vec<TR>(xb + pix * xs, x[u]);
+                load_vec<TR>(gb + pix * gs, dy[u]);
             }
-            const float gh = dy[e] * (d > 0.f ? 1.f : alpha) * sc;
-            o[e] = rstd * (gh - bm[(ch0 + e) * 2] - xh * bm[(ch0 + e) * 2 + 1]);
         }
-        store_vec<TR>(p.out + (gp * p.out_pitch + p.out_coff + ch0) * ESZ, o);
+#pragma unroll
+        for (int u = 0; u < NORM_U; ++u) {
+            const int pix = pix0 + u * l.rows;
+            if (pix < l.pend) {
+                float o[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const float xh = (x[u][e] - mean[e]) * rstd[e];
+                    float d = xh, sc = 1.f;
+                    if (p.drop_thresh) {
+                        const bool keep = dropout_keep(p.seed, p.layer, (unsigned long long)(img_pix + pix) * p.c + l.ch0 + e, p.drop_thresh);
+                        sc = keep ? p.drop_scale : 0.f;
+                        d = xh * sc;
+                    }
+                    const float gh = dy[u][e] * (d > 0.f ? 1.f : alpha) * sc;
+                    o[e] = rstd[e] * (gh - b1[e] - xh * b2[e]);
+                }
+                store_vec<TR>(ob + pix * os, o);
+            }
+        }
     }
 }
 
@@ -288,20 +352,26 @@ int check_launch(const char* what) {
 
 }  // namespace
 
-int norm_bwd_reduce_blocks(int npix, int c) {
-    // about 16 pixel sweeps per thread: a sweep covers 256 / (16-byte vectors per pixel) pixels
-    int per_block = 2048;
-    if (c > 1) {
-        int vec_pp = c / 4; if (vec_pp > 256) vec_pp = 256; if (vec_pp < 1) vec_pp = 1;   // >= vectors per pixel in either dtype
-        per_block = (256 / vec_pp) * 16 * 2;
-        if (per_block < 64) per_block = 64;
-        if (per_block > 2048) per_block = 2048;
-    }
+// workgroups per image of the streaming kernels: `sweeps` pixel sweeps per thread (a sweep of the workgroup
+// covers 256 / (16-byte vectors per pixel) pixels)
+static int norm_blocks(int npix, int c, int vec, int sweeps, int cap) {
+    const int cv_n = c / vec;
+    const int rows = 256 / cv_n;
+    const int per_block = rows * sweeps;
     int g = (npix + per_block - 1) / per_block;
-    const int cap = c == 1 ? 128 : 256;
     if (g < 1) g = 1;
     if (g > cap) g = cap;
     return g;
+}
+
+int norm_bwd_reduce_blocks(int npix, int c) {
+    if (c == 1) {
+        int g = (npix + 2047) / 2048;
+        return g < 1 ? 1 : g > 128 ? 128 : g;
+    }
+    // one count for both dtypes (the caller sizes the slope-gradient slots from it): 32 sweeps of an fp32
+    // workgroup = 16 sweeps of a bf16 one
+    return norm_blocks(npix, c, 4, 32, 256);
 }
 
 // dtype: 0 fp32, 1 bf16.  c == 1 selects the planar fp32 kernels (pitch must be 1, dtype 0).
@@ -314,8 +384,8 @@ int launch_norm_fwd(int dtype, const NormParams& p, hipStream_t st) {
     }
     const int vec = dtype ? 8 : 4;
     MI_CHECK(p.c % vec == 0, "channels must be a multiple of the 16-byte vector");
-    const long long nvec = (long long)p.npix * (p.c / vec);
-    const int gx = (int)((nvec + 256 * NORM_ITEMS - 1) / (256 * NORM_ITEMS));
+    MI_CHECK(p.c / vec <= 256, "too many channels for the norm kernels");
+    const int gx = norm_blocks(p.npix, p.c, vec, 8, 65535);
     const size_t lds = (size_t)p.c * 2 * sizeof(float);
     if (dtype) hipLaunchKernelGGL(norm_fwd_kernel<BF16>, dim3(gx, p.nb), dim3(256), lds, st, p);
     else hipLaunchKernelGGL(norm_fwd_kernel<F32>, dim3(gx, p.nb), dim3(256), lds, st, p);
@@ -342,8 +412,7 @@ int launch_norm_bwd(int dtype, const NormParams& p, hipStream_t st) {
     if (dtype) hipLaunchKernelGGL(norm_bwd_reduce_kernel<BF16>, dim3(gr, p.nb), dim3(256), lds_r, st, p);
     else hipLaunchKernelGGL(norm_bwd_reduce_kernel<F32>, dim3(gr, p.nb), dim3(256), lds_r, st, p);
     if (int r = check_launch("norm_bwd_reduce")) return r;
-    const long long nvec = (long long)p.npix * (p.c / vec);
-    const int gx = (int)((nvec + 256 * NORM_ITEMS - 1) / (256 * NORM_ITEMS));
+    const int gx = norm_blocks(p.npix, p.c, vec, 8, 65535);
     if (dtype) hipLaunchKernelGGL(norm_bwd_apply_kernel<BF16>, dim3(gx, p.nb), dim3(256), lds, st, p);
     else hipLaunchKernelGGL(norm_bwd_apply_kernel<F32>, dim3(gx, p.nb), dim3(256), lds, st, p);
     return check_launch("norm_bwd_apply");
