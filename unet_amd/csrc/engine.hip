@@ -198,7 +198,7 @@ struct Builder {
     bool add_igemm(std::vector<Step>& list, const std::string& layer, const ConvShape& cs, int dir, const Ten& in0,
                    int in0_c, const Ten* in1, int K, int N, size_t w_off, const char* bias_name, int bias_c0,
                    const Ten& out, const Ten* addend, size_t stats_off, int stats_c, int nstat, int kidx_out[MI_MAX_TAPS],
-                   int* ntaps_out) {
+                   int* ntaps_out, const Ten* out1 = nullptr, int out0_c = 0) {
         Step& s = push(list, K_IGEMM, layer);
         IgemmParams& p = s.ig;
         if (!igemm_geometry(cs, dir, p, kidx_out, ntaps_out)) { mi_set_error("igemm geometry: odd size under stride 2"); return false; }
@@ -209,6 +209,8 @@ struct Builder {
         REL(s, p, w, B_ARENA, w_off);
         if (bias_name) { REL(s, p, bias, B_PARAMS, poff(bias_name) * sizeof(float)); p.bias_c0 = bias_c0; }
         REL(s, p, out, out.base, out.off); p.out_pitch = out.pitch; p.out_coff = out.coff;
+        p.out0_c = N;
+        if (out1) { REL(s, p, out1, out1->base, out1->off); p.out1_pitch = out1->pitch; p.out1_coff = out1->coff; p.out0_c = out0_c; }
         if (addend) { REL(s, p, addend, addend->base, addend->off); p.add_pitch = addend->pitch; p.add_coff = addend->coff; }
         if (stats_off != (size_t)-1) { REL(s, p, stats, B_ARENA, stats_off); p.stats_c = stats_c; p.nstat = nstat; }
         int cps, nfrag;
@@ -237,13 +239,8 @@ struct Builder {
         if (f1) { REL(s, p, f1, f1->base, f1->off); p.f1_pitch = f1->pitch; p.f1_coff = f1->coff; }
         REL(s, p, s, sten.base, sten.off); p.s_pitch = sten.pitch; p.s_coff = sten.coff;
         int ff, sf, wf, wsn;
-        p.nsplit = 1;
+        wgrad_choose_split(u.dt, p);
         wgrad_config(u.dt, p, &ff, &sf, &wf, &wsn);
-        const int blocks = (F / (16 * ff * wf)) * (S / (16 * sf * wsn)) * p.ntapg;
-        int nsplit = (256 + blocks - 1) / blocks;
-        if (nsplit > p.tiles_total) nsplit = p.tiles_total;
-        if (nsplit < 1) nsplit = 1;
-        p.nsplit = nsplit;
         const int slabs = wgrad_slabs(u.dt, p);
         const size_t po = alloc((size_t)slabs * p.ntaps_total * F * S * sizeof(float));
         const size_t pb = alloc((size_t)slabs * F * sizeof(float));
@@ -392,18 +389,22 @@ bool build(mi_unet& u) {
         u.off_bstats = B.alloc(tot); u.bstats_bytes = tot;
     }
     std::vector<int> Pcat(L);
-    std::vector<Ten> cat(L), gcat(L);
+    // the skip concatenation [encoder output | decoder output] of level l is kept as two contiguous tensors
+    // (A: c[l] channels, B: the rest): consumers take them as a dual-source operand, producers as a dual
+    // destination, and every access moves whole cache lines even when a pixel has only 16 channels
+    std::vector<Ten> catA(L), catB(L), gcatA(L), gcatB(L);
     for (int l = 0; l <= L - 2; ++l) {
         Pcat[l] = (l < L - 2) ? 2 * c[l] : c[L - 2] + c[L - 1];
-        cat[l] = B.new_tensor(l + 1, Pcat[l], esz);
-        if (train) gcat[l] = B.new_tensor(l + 1, Pcat[l], esz);
+        catA[l] = B.new_tensor(l + 1, c[l], esz);
+        catB[l] = B.new_tensor(l + 1, Pcat[l] - c[l], esz);
+        if (train) { gcatA[l] = B.new_tensor(l + 1, c[l], esz); gcatB[l] = B.new_tensor(l + 1, Pcat[l] - c[l], esz); }
     }
     Ten xin; xin.base = B_XIN; xin.off = 0; xin.pitch = 1; xin.coff = 0;
     Ten logits; logits.base = B_LOGITS; logits.pitch = 1;
     Ten dlogits; dlogits.base = B_DLOGITS; dlogits.pitch = 1;
 
     struct UnitSave { Ten raw; size_t stats; Ten act; std::string alpha; int lid; size_t wfwd, wdg; std::string wname, bname; };
-    struct DownSave { Ten dnA; std::vector<UnitSave> un; size_t wf, wd; int ntaps_d; };
+    struct DownSave { Ten raw0, res; std::vector<UnitSave> un; size_t wf, wd; int ntaps_d; };
     std::vector<DownSave> down(L - 1);
     struct BotSave { std::vector<UnitSave> un; Ten res; bool has_res_conv; size_t wres_f, wres_d; } bot;
     struct UpSave { Ten rawT, actT, rawU; size_t statsT, statsU; int lidT, lidU; size_t wT_f, wT_d, wU_f, wU_d; } ;
@@ -435,7 +436,8 @@ bool build(mi_unet& u) {
         const std::string P = dprefix[l];
         const std::string lname = "down" + std::to_string(l);
         DownSave& D = down[l];
-        D.dnA = B.new_tensor(l + 1, 2 * cout, esz);
+        D.raw0 = B.new_tensor(l + 1, cout, esz);   // unit0 conv output (before the norm)
+        D.res = B.new_tensor(l + 1, cout, esz);    // residual conv output
         D.un.resize(R);
         for (int su = 0; su < R; ++su) {
             D.un[su].stats = B.stats_alloc((size_t)nb * MI_NSLOT * cout * 2 * sizeof(double));
@@ -448,7 +450,8 @@ bool build(mi_unet& u) {
             Step& s = B.push(u.fwd, K_C1_FWD, lname + ".unit0+residual conv s2 (1->2C)");
             C1Params& p = s.c1;
             REL(s, p, x1, B_XIN, 0);
-            REL(s, p, y_out, B_ARENA, D.dnA.off); p.y_pitch = 2 * cout; p.y_coff = 0; p.N = 2 * cout;
+            REL(s, p, y_out, B_ARENA, D.raw0.off); p.y_pitch = cout; p.y_coff = 0; p.N = 2 * cout;
+            REL(s, p, y2_out, B_ARENA, D.res.off); p.y2o_pitch = cout; p.y2o_coff = 0; p.n_o1 = cout;
             REL(s, p, w, B_PARAMS, B.poff(D.un[0].wname) * sizeof(float));
             REL(s, p, w2, B_PARAMS, B.poff(P + ".residual.weight") * sizeof(float)); p.n_w1 = cout;
             REL(s, p, bias, B_PARAMS, B.poff(P + ".residual.bias") * sizeof(float)); p.bias_c0 = cout;
@@ -461,16 +464,17 @@ bool build(mi_unet& u) {
         } else {
             ConvShape cs = B.shape(0, 3, 2, cin, 2 * cout, l);
             D.wf = B.packed_alloc(KK, 2 * cout, cin);
-            Ten in = cat[l - 1];
+            Ten in = catA[l - 1];
             if (!B.add_igemm(u.fwd, lname + ".unit0+residual conv s2", cs, DIR_FWD, in, cin, nullptr, cin, 2 * cout, D.wf,
-                             (P + ".residual.bias").c_str(), cout, D.dnA, nullptr, D.un[0].stats, cout, cout, kidx, &ntaps))
+                             (P + ".residual.bias").c_str(), cout, D.raw0, nullptr, D.un[0].stats, cout, cout, kidx, &ntaps,
+                             &D.res, cout))
                 return false;
             B.add_pack(false, D.wf, D.un[0].wname, cout, cin, ntaps, kidx, cin * KK, KK, 2 * cout, cin, 0, 0);
             B.add_pack(false, D.wf, P + ".residual.weight", cout, cin, ntaps, kidx, cin * KK, KK, 2 * cout, cin, cout, 0);
         }
-        D.un[0].raw = D.dnA;  // channels [0, cout)
+        D.un[0].raw = D.raw0;
         for (int su = 0; su < R; ++su) {
-            Ten res = D.dnA; res.coff = cout;
+            Ten res = D.res;
             if (su < R - 1) {
                 D.un[su].act = B.new_tensor(l + 1, cout, esz);
                 B.add_norm_fwd(lname + ".unit" + std::to_string(su) + " norm+prelu", l + 1, cout, dt, D.un[su].raw,
@@ -484,7 +488,7 @@ bool build(mi_unet& u) {
                     return false;
                 B.add_pack(false, D.un[su + 1].wfwd, D.un[su + 1].wname, cout, cout, ntaps, kidx, cout * KK, KK, cout, cout, 0, 0);
             } else {
-                Ten out = cat[l]; out.coff = 0;
+                Ten out = catA[l];
                 B.add_norm_fwd(lname + ".unit" + std::to_string(su) + " norm+prelu+residual", l + 1, cout, dt, D.un[su].raw,
                                D.un[su].stats, D.un[su].alpha, &res, out, D.un[su].lid);
             }
@@ -496,7 +500,7 @@ bool build(mi_unet& u) {
         const std::string P = botprefix;
         bot.un.resize(R);
         bot.has_res_conv = cin != cout;
-        Ten in = cat[L - 2]; in.coff = 0;
+        Ten in = catA[L - 2];
         for (int su = 0; su < R; ++su) {
             UnitSave& U = bot.un[su];
             U.stats = B.stats_alloc((size_t)nb * MI_NSLOT * cout * 2 * sizeof(double));
@@ -531,7 +535,7 @@ bool build(mi_unet& u) {
                 B.add_norm_fwd("bottom.unit" + std::to_string(su) + " norm+prelu", res, cout, dt, U.raw, U.stats, U.alpha,
                                nullptr, U.act, U.lid);
             } else {
-                Ten out = cat[L - 2]; out.coff = cin;
+                Ten out = catB[L - 2];
                 B.add_norm_fwd("bottom.unit" + std::to_string(su) + " norm+prelu+residual", res, cout, dt, U.raw, U.stats,
                                U.alpha, &bot.res, out, U.lid);
             }
@@ -551,7 +555,7 @@ bool build(mi_unet& u) {
             U.statsU = B.stats_alloc((size_t)nb * MI_NSLOT * outc * 2 * sizeof(double));
             ConvShape ct = B.shape(1, 3, 2, K, outc, l + 1);
             U.wT_f = B.packed_alloc(KK, outc, K);
-            if (!B.add_igemm(u.fwd, lname + ".convT", ct, DIR_FWD, cat[l], K, nullptr, K, outc, U.wT_f, nullptr, 0, U.rawT,
+            if (!B.add_igemm(u.fwd, lname + ".convT", ct, DIR_FWD, catA[l], c[l], &catB[l], K, outc, U.wT_f, nullptr, 0, U.rawT,
                              nullptr, U.statsT, outc, outc, kidx, &ntaps))
                 return false;
             B.add_pack(false, U.wT_f, P + ".0.conv.weight", outc, K, ntaps, kidx, KK, outc * KK, outc, K, 0, 0);
@@ -562,7 +566,7 @@ bool build(mi_unet& u) {
                              U.rawU, nullptr, U.statsU, outc, outc, kidx, &ntaps))
                 return false;
             B.add_pack(false, U.wU_f, P + ".1.conv.unit0.conv.weight", outc, outc, ntaps, kidx, outc * KK, KK, outc, outc, 0, 0);
-            Ten out = cat[l - 1]; out.coff = c[l - 1];
+            Ten out = catB[l - 1];
             B.add_norm_fwd(lname + ".ru norm+prelu+residual", l, outc, dt, U.rawU, U.statsU, P + ".1.conv.unit0.adn.A.weight",
                            &U.actT, out, U.lidU);
         } else {
@@ -571,7 +575,8 @@ bool build(mi_unet& u) {
             {
                 Step& s = B.push(u.fwd, K_C1_T, lname + ".convT (2C->1)");
                 C1Params& p = s.c1;
-                REL(s, p, y, B_ARENA, cat[0].off); p.y_pitch = K; p.y_coff = 0; p.N = K;
+                REL(s, p, y, B_ARENA, catA[0].off); p.y_pitch = c[0]; p.y_coff = 0; p.N = K;
+                REL(s, p, y2, B_ARENA, catB[0].off); p.y2_pitch = K - c[0]; p.y2_coff = 0; p.n_y1 = c[0];
                 REL(s, p, x1_out, B_ARENA, U.rawT.off);
                 REL(s, p, w, B_PARAMS, B.poff(P + ".0.conv.weight") * sizeof(float));
                 REL(s, p, stats, B_ARENA, U.statsT); p.stats_c = 1; p.nstat = 1;
@@ -653,7 +658,8 @@ bool build(mi_unet& u) {
                 Step& s = B.push(u.bwd, K_C1_FWD, "up0.convT dgrad (1->2C conv s2)");
                 C1Params& p = s.c1;
                 REL(s, p, x1, B_ARENA, g_rawT.off);
-                REL(s, p, y_out, B_ARENA, gcat[0].off); p.y_pitch = K; p.y_coff = 0; p.N = K;
+                REL(s, p, y_out, B_ARENA, gcatA[0].off); p.y_pitch = c[0]; p.y_coff = 0; p.N = K;
+                REL(s, p, y2_out, B_ARENA, gcatB[0].off); p.y2o_pitch = K - c[0]; p.y2o_coff = 0; p.n_o1 = c[0];
                 REL(s, p, w, B_PARAMS, B.poff(P + ".0.conv.weight") * sizeof(float)); p.n_w1 = K;
                 p.ndim = nd; p.nb = nb;
                 for (int d = 0; d < 3; ++d) { p.fd[d] = u.rd[0][d]; p.cd[d] = u.rd[1][d]; }
@@ -664,9 +670,10 @@ bool build(mi_unet& u) {
             {
                 Step& s = B.push(u.bwd, K_C1_WGRAD, "up0.convT wgrad");
                 C1Params& p = s.c1;
-                REL(s, p, y, B_ARENA, cat[0].off); p.y_pitch = K; p.y_coff = 0; p.N = K;
+                REL(s, p, y, B_ARENA, catA[0].off); p.y_pitch = c[0]; p.y_coff = 0; p.N = K;
+                REL(s, p, y2, B_ARENA, catB[0].off); p.y2_pitch = K - c[0]; p.y2_coff = 0;
                 REL(s, p, x1, B_ARENA, g_rawT.off);
-                p.ndim = nd; p.nb = nb; p.n_y1 = K;
+                p.ndim = nd; p.nb = nb; p.n_y1 = c[0];
                 for (int d = 0; d < 3; ++d) { p.fd[d] = u.rd[0][d]; p.cd[d] = u.rd[1][d]; }
                 p.nsplit = c1_wgrad_slabs(p.N, p.cd);
                 po = B.alloc((size_t)p.nsplit * KK * K * sizeof(float)); pb = B.alloc((size_t)p.nsplit * K * sizeof(float));
@@ -684,7 +691,7 @@ bool build(mi_unet& u) {
             const std::string lname = "up" + std::to_string(l);
             UpSave& U = up[l];
             const int outc = c[l - 1], K = Pcat[l];
-            Ten dout = gcat[l - 1]; dout.coff = c[l - 1];
+            Ten dout = gcatB[l - 1];
             Ten g_rawU = B.new_tensor(l, outc, esz), g_actT = B.new_tensor(l, outc, esz), g_rawT = B.new_tensor(l, outc, esz);
             B.add_norm_bwd(lname + ".ru norm+prelu bwd", l, outc, dt, dout, U.rawU, U.statsU, P + ".1.conv.unit0.adn.A.weight", g_rawU, U.lidU);
             ConvShape cu = B.shape(0, 3, 1, outc, outc, l);
@@ -699,10 +706,10 @@ bool build(mi_unet& u) {
             ConvShape ct = B.shape(1, 3, 2, K, outc, l + 1);
             U.wT_d = B.packed_alloc(KK, K, outc);
             if (!B.add_igemm(u.bwd, lname + ".convT dgrad", ct, DIR_DGRAD, g_rawT, outc, nullptr, outc, K, U.wT_d, nullptr, 0,
-                             gcat[l], nullptr, (size_t)-1, 0, 0, kidx, &ntaps))
+                             gcatA[l], nullptr, (size_t)-1, 0, 0, kidx, &ntaps, &gcatB[l], c[l]))
                 return false;
             B.add_pack(true, U.wT_d, P + ".0.conv.weight", K, outc, ntaps, kidx, outc * KK, KK, K, outc, 0, 0);
-            B.add_wgrad(lname + ".convT wgrad", ct, cat[l], K, nullptr, K, g_rawT, outc, &po, &pb, &nslab, &nt);
+            B.add_wgrad(lname + ".convT wgrad", ct, catA[l], c[l], &catB[l], K, g_rawT, outc, &po, &pb, &nslab, &nt);
             B.add_reduce(po, pb, nslab, nt, K, outc, 0, K, KK, nat, P + ".0.conv.weight", "");
             B.add_scalar_reduce(0, 0, P + ".0.conv.bias", outc);
         }
@@ -712,9 +719,9 @@ bool build(mi_unet& u) {
         {
             const int cin = c[L - 2], cout = c[L - 1], res = L - 1;
             const std::string P = botprefix;
-            Ten dout = gcat[L - 2]; dout.coff = cin;
-            Ten gin = gcat[L - 2]; gin.coff = 0;
-            Ten in = cat[L - 2]; in.coff = 0;
+            Ten dout = gcatB[L - 2];
+            Ten gin = gcatA[L - 2];
+            Ten in = catA[L - 2];
             Ten g_raw = B.new_tensor(res, cout, esz);
             B.add_norm_bwd("bottom.unit" + std::to_string(R - 1) + " norm+prelu bwd", res, cout, dt, dout, bot.un[R - 1].raw,
                            bot.un[R - 1].stats, bot.un[R - 1].alpha, g_raw, bot.un[R - 1].lid);
@@ -772,7 +779,7 @@ bool build(mi_unet& u) {
             const std::string P = dprefix[l];
             const std::string lname = "down" + std::to_string(l);
             DownSave& D = down[l];
-            Ten dout = gcat[l]; dout.coff = 0;
+            Ten dout = gcatA[l];
             Ten g_raw = B.new_tensor(l + 1, cout, esz);
             B.add_norm_bwd(lname + ".unit" + std::to_string(R - 1) + " norm+prelu bwd", l + 1, cout, dt, dout, D.un[R - 1].raw,
                            D.un[R - 1].stats, D.un[R - 1].alpha, g_raw, D.un[R - 1].lid);
@@ -795,8 +802,8 @@ bool build(mi_unet& u) {
             }
             if (l > 0) {
                 ConvShape cs = B.shape(0, 3, 2, cin, 2 * cout, l);
-                Ten gin = gcat[l - 1]; gin.coff = 0;
-                Ten in = cat[l - 1]; in.coff = 0;
+                Ten gin = gcatA[l - 1];
+                Ten in = catA[l - 1];
                 D.wd = B.packed_alloc(KK, cin, 2 * cout);
                 if (!B.add_igemm(u.bwd, lname + ".unit0+residual conv s2 dgrad (+=)", cs, DIR_DGRAD, g_raw, cout, &dout, 2 * cout,
                                  cin, D.wd, nullptr, 0, gin, &gin, (size_t)-1, 0, 0, kidx, &ntaps))

@@ -219,7 +219,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] += a[j];
                 }
-                store_n<TR, 4>(p.out + (op * p.out_pitch + p.out_coff + ch) * ESZ, v);
+                char* dst = ch < p.out0_c ? p.out + (op * p.out_pitch + p.out_coff + ch) * ESZ
+                                          : p.out1 + (op * p.out1_pitch + p.out1_coff + ch - p.out0_c) * ESZ;
+                store_n<TR, 4>(dst, v);
             } else {
 #pragma unroll
                 for (int pf = 0; pf < NFRAG / 2; ++pf) {
@@ -237,7 +239,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) v[j] += a[j];
                     }
-                    store_n<TR, 8>(p.out + (op * p.out_pitch + p.out_coff + ch) * ESZ, v);
+                    char* dst = ch < p.out0_c ? p.out + (op * p.out_pitch + p.out_coff + ch) * ESZ
+                                              : p.out1 + (op * p.out1_pitch + p.out1_coff + ch - p.out0_c) * ESZ;
+                    store_n<TR, 8>(dst, v);
                 }
             }
         }
@@ -464,7 +468,9 @@ __global__ __launch_bounds__(256) void igemm2d_kernel(const IgemmParams p) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] += a[j];
                     }
-                    store_n<TR, 4>(p.out + (op * p.out_pitch + p.out_coff + ch) * ESZ, v);
+                    char* dst = ch < p.out0_c ? p.out + (op * p.out_pitch + p.out_coff + ch) * ESZ
+                                              : p.out1 + (op * p.out1_pitch + p.out1_coff + ch - p.out0_c) * ESZ;
+                    store_n<TR, 4>(dst, v);
                 } else {
 #pragma unroll
                     for (int pf = 0; pf < NFRAG / 2; ++pf) {
@@ -482,7 +488,9 @@ __global__ __launch_bounds__(256) void igemm2d_kernel(const IgemmParams p) {
 #pragma unroll
                             for (int j = 0; j < 8; ++j) v[j] += a[j];
                         }
-                        store_n<TR, 8>(p.out + (op * p.out_pitch + p.out_coff + ch) * ESZ, v);
+                        char* dst = ch < p.out0_c ? p.out + (op * p.out_pitch + p.out_coff + ch) * ESZ
+                                                  : p.out1 + (op * p.out1_pitch + p.out1_coff + ch - p.out0_c) * ESZ;
+                        store_n<TR, 8>(dst, v);
                     }
                 }
             }
@@ -873,6 +881,7 @@ unsigned magic_of(int d) { return d <= 1 ? 0u : (unsigned)(0x100000000ull / (uns
 template <class TR, int CPS, int NFRAG>
 int launch_igemm_t(const IgemmParams& pin, hipStream_t st) {
     IgemmParams p = pin;
+    if (!p.out1) p.out0_c = p.N;
     p.mg_pd2 = magic_of(p.pd[2]); p.mg_pd12 = magic_of(p.pd[1] * p.pd[2]);
     constexpr int PITCH = CPS * 16 + 16;
     const int PP = p.pd[0] * p.pd[1] * p.pd[2];
@@ -901,6 +910,7 @@ inline int igemm2d_ks(const IgemmParams& p) {
 template <class TR, int CPS, int NFRAG, int KS>
 int launch_igemm2d_t(const IgemmParams& pin, hipStream_t st) {
     IgemmParams p = pin;
+    if (!p.out1) p.out0_c = p.N;
     constexpr int PITCH = CPS * 16 + 16, NT = NFRAG * 16;
     constexpr int PD = KS == 3 ? 18 : KS == 2 ? 17 : 16;
     constexpr int MAXTAP = KS == 3 ? 9 : KS == 2 ? 4 : 1;
@@ -983,6 +993,7 @@ int launch_igemm(int dtype, const IgemmParams& p, hipStream_t st) {
     MI_CHECK(p.K % (32 / esz) == 0, "contraction channels must be a multiple of 32 bytes");
     MI_CHECK(p.in0_c >= p.K || p.in0_c % (32 / esz) == 0, "first-source channel count must be a multiple of 32 bytes");
     MI_CHECK(p.N % 16 == 0, "output channels must be a multiple of 16");
+    MI_CHECK(!p.out1 || (p.out0_c % 16 == 0 && p.out0_c > 0 && p.out0_c < p.N), "first-destination channel count must be a multiple of 16");
     MI_CHECK(p.tlog[0] + p.tlog[1] + p.tlog[2] == 8, "tile must hold 256 base pixels");
     MI_CHECK(p.tapg >= 1 && p.tapg <= 9, "tap group size");
     MI_CHECK(igemm_lds_for(p, cps, nfrag) <= 160 * 1024, "LDS images do not fit");
@@ -1018,7 +1029,8 @@ static size_t wgrad_lds_for(int dtype, const WgradParams& p, int FB, int SB) {
 // arrangement follow), shrunk until the LDS images fit.
 void wgrad_config(int dtype, const WgradParams& p, int* ff, int* sf, int* wf, int* wsn) {
     auto pick = [](int c, int maxblk) { int b = maxblk; while (b > 16 && c % b) b >>= 1; return b; };
-    const int maxb = dtype ? 64 : 32;
+    int maxb = dtype ? 64 : 32;
+    if (const char* e = getenv("MI_WG_MAXB")) { const int v = atoi(e); if (v >= 16 && v < maxb) maxb = v; }
     int FB = pick(p.F, maxb), SB = pick(p.S, maxb);
     if (p.f0_c < p.F) while (FB > 16 && p.f0_c % FB) FB >>= 1;
     while (wgrad_lds_for(dtype, p, FB, SB) > kLdsBudget && (SB > 16 || FB > 16)) {
@@ -1026,6 +1038,21 @@ void wgrad_config(int dtype, const WgradParams& p, int* ff, int* sf, int* wf, in
     }
     *ff = FB >= 32 ? 2 : 1; *wf = FB / (16 * *ff);
     *sf = SB >= 32 ? 2 : 1; *wsn = SB / (16 * *sf);
+}
+
+// Chooses how many workgroups split the pixels of each (F block, S block, tap group): enough workgroups to
+// fill the chip, never more than there are tiles.
+void wgrad_choose_split(int dtype, WgradParams& p) {
+    int ff, sf, wf, wsn;
+    p.nsplit = 1;
+    wgrad_config(dtype, p, &ff, &sf, &wf, &wsn);
+    const int blocks = (p.F / (16 * ff * wf)) * (p.S / (16 * sf * wsn)) * p.ntapg;
+    int target = 256;
+    if (const char* e = getenv("MI_WG_WGS")) { const int v = atoi(e); if (v > 0) target = v; }
+    int nsplit = (target + blocks - 1) / blocks;
+    if (nsplit > p.tiles_total) nsplit = p.tiles_total;
+    if (nsplit < 1) nsplit = 1;
+    p.nsplit = nsplit;
 }
 
 int wgrad_slabs(int dtype, const WgradParams& p) {

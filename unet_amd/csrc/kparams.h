@@ -19,6 +19,7 @@ struct IgemmParams {
     const char* w;                          // packed weights [tap][N][K], storage type of the activations
     const float* bias; int bias_c0;         // bias[ch-bias_c0] is added to output channels >= bias_c0 (null: none)
     char* out; int out_pitch, out_coff, N;
+    char* out1; int out1_pitch, out1_coff, out0_c;  // optional second destination: output channels >= out0_c go to out1 (null: none)
     const char* addend; int add_pitch, add_coff;  // optional tensor added in the epilogue (may alias out)
     double* stats; int stats_c, nstat;      // per-(image,slot,channel) {sum, sum of squares} of the first nstat channels
     int nb;
@@ -97,8 +98,10 @@ struct C1Params {
     const float* x1; float* x1_out;         // fine one-channel tensor (input / output)
     const char* y; char* y_out;             // coarse N-channel tensor (input / output)
     int y_pitch, y_coff, N;
-    const char* y2; int y2_pitch, y2_coff;  // weight gradient: channels >= n_y1 are read from this tensor
+    const char* y2; int y2_pitch, y2_coff;  // input side: channels >= n_y1 are read from this tensor (n_y1 >= N: single source)
     int n_y1;
+    char* y2_out; int y2o_pitch, y2o_coff;  // output side: channels >= n_o1 are written to this tensor (null: single destination)
+    int n_o1;
     const float* w; const float* w2; int n_w1;  // weights [n][KK]; channels >= n_w1 read w2[(n-n_w1)][KK]
     const float* bias; int bias_c0;
     double* stats; int stats_c, nstat;
@@ -124,6 +127,7 @@ int launch_reduce(const ReduceDesc* d_descs, int ndesc, int max_elems, hipStream
 int launch_pack(int dtype, const PackDesc* d_descs, int ndesc, int max_elems, hipStream_t st);
 int launch_reduce_one(const ReduceDesc& d, hipStream_t st);
 int c1_wgrad_slabs(int N, const int cd[3]);
+void wgrad_choose_split(int dtype, WgradParams& p);
 int launch_pack_one(int dtype, const PackDesc& d, hipStream_t st);
 int launch_norm_fwd(int dtype, const NormParams& p, hipStream_t st);
 int launch_norm_bwd(int dtype, const NormParams& p, hipStream_t st);

@@ -97,14 +97,7 @@ static void wgrad_params(const mi_conv_desc* d, WgradParams& p) {
     p.F = d->transposed ? d->cin : d->cout;
     p.S = d->transposed ? d->cout : d->cin;
     p.f0_c = p.F;
-    p.nsplit = 1;
-    int ff, sf, wf, wsn;
-    wgrad_config(d->dtype, p, &ff, &sf, &wf, &wsn);
-    const int blocks = (p.F / (16 * ff * wf)) * (p.S / (16 * sf * wsn)) * p.ntapg;
-    int nsplit = (256 + blocks - 1) / blocks;
-    if (nsplit > p.tiles_total) nsplit = p.tiles_total;
-    if (nsplit < 1) nsplit = 1;
-    p.nsplit = nsplit;
+    wgrad_choose_split(d->dtype, p);
 }
 
 size_t mi_conv_wgrad_workspace_bytes(const mi_conv_desc* d) {

@@ -94,7 +94,9 @@ __global__ __launch_bounds__(256) void c1_s2_fwd_kernel(const C1Params p) {
                 s2[e] += acc[r][e] * acc[r][e];
             }
             const size_t gp = (size_t)img * cpix + ((size_t)cz * p.cd[1] + cy) * p.cd[2] + cx;
-            store_n<TR, 8>(p.y_out + (gp * p.y_pitch + p.y_coff + grp * 8) * ESZ, o);
+            char* dst = (p.y2_out && grp * 8 >= p.n_o1) ? p.y2_out + (gp * p.y2o_pitch + p.y2o_coff + grp * 8 - p.n_o1) * ESZ
+                                                       : p.y_out + (gp * p.y_pitch + p.y_coff + grp * 8) * ESZ;
+            store_n<TR, 8>(dst, o);
         }
     }
     if (p.stats) {
@@ -153,9 +155,10 @@ __global__ __launch_bounds__(256) void c1_s2_T_kernel(const C1Params p) {
         if (cz < p.cd[0] && cy < p.cd[1] && cx < p.cd[2]) {
             const size_t gp = (size_t)img * cpix + ((size_t)cz * p.cd[1] + cy) * p.cd[2] + cx;
             const char* src = p.y + (gp * p.y_pitch + p.y_coff) * ESZ;
+            const char* src2 = p.y2 ? p.y2 + (gp * p.y2_pitch + p.y2_coff) * ESZ : nullptr;
             for (int n0 = 0; n0 < N; n0 += 8) {
                 float v[8];
-                load_n<TR, 8>(src + n0 * ESZ, v);
+                load_n<TR, 8>((src2 && n0 >= p.n_y1) ? src2 + (n0 - p.n_y1) * ESZ : src + n0 * ESZ, v);
 #pragma unroll
                 for (int k = 0; k < KK; ++k) {
                     const float4 a = *reinterpret_cast<const float4*>(wl + k * N + n0);
@@ -515,6 +518,7 @@ int run_c1_T(const C1Params& p, hipStream_t st) {
 
 int launch_c1_s2_fwd(int dtype, const C1Params& p, hipStream_t st) {
     MI_CHECK(p.N % 8 == 0 && p.N >= 8 && p.N <= 256, "N must be a multiple of 8, at most 256");
+    MI_CHECK(!p.y2_out || (p.n_o1 % 8 == 0 && p.n_o1 > 0), "second destination must start at a multiple of 8 channels");
     MI_CHECK((long long)p.nb * p.cd[0] <= 65535, "batch x depth exceeds the grid limit");
     if (p.ndim == 3) return dtype ? run_c1_fwd<BF16, 3>(p, st) : run_c1_fwd<F32, 3>(p, st);
     return dtype ? run_c1_fwd<BF16, 1>(p, st) : run_c1_fwd<F32, 1>(p, st);
@@ -522,6 +526,7 @@ int launch_c1_s2_fwd(int dtype, const C1Params& p, hipStream_t st) {
 
 int launch_c1_s2_T(int dtype, const C1Params& p, hipStream_t st) {
     MI_CHECK(p.N % 8 == 0 && p.N >= 8 && p.N <= 256, "N must be a multiple of 8, at most 256");
+    MI_CHECK(!p.y2 || (p.n_y1 % 8 == 0 && p.n_y1 > 0), "second source must start at a multiple of 8 channels");
     MI_CHECK(p.fd[2] == 2 * p.cd[2] && p.fd[1] == 2 * p.cd[1] && (p.ndim == 2 || p.fd[0] == 2 * p.cd[0]),
              "fine dims must be twice the coarse dims");
     MI_CHECK((long long)p.nb * p.cd[0] <= 65535, "batch x depth exceeds the grid limit");
