@@ -564,7 +564,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     else { fsrc = p.f1; fpitch = p.f1_pitch; fcoff = p.f1_coff + fb0 - p.f0_c; }
     const int tiles_per_img = p.ntile[0] * p.ntile[1] * p.ntile[2];
 
-    for (int tile = blockIdx.x; tile < p.tiles_total; tile += p.nsplit) {
+    // One tile = 256 base pixels of one image.  load_tile() issues the global loads of a tile into registers
+    // (F: FVN vectors per thread; S patch: up to SMAX), store_tile() writes them to LDS.  When the patch fits
+    // the register budget the loads of tile i+1 are in flight while tile i is multiplied.
+    constexpr int FVPP = FB * ESZ / 16;      // 16-byte vectors per F pixel = F vectors per thread
+    constexpr int SVPP = SB * ESZ / 16;
+    constexpr int SMAX = 12;
+    const int stotal = PP * SVPP;
+    const int nsv = (stotal + 255) >> 8;
+    uint4 fv[FVPP], sv[SMAX];
+    auto load_tile = [&](int tile, bool with_s) {
         const int img = tile / tiles_per_img;
         int tr = tile - img * tiles_per_img;
         const int txi = tr % p.ntile[2]; tr /= p.ntile[2];
@@ -572,63 +581,93 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
         const int bz0 = tzi << p.tlog[0], by0 = tyi << p.tlog[1], bx0 = txi << p.tlog[2];
         const int iz0 = bz0 * p.ss + p.omin[0] + p.tg_zoff[tgi], iy0 = by0 * p.ss + p.omin[1],
                   ix0 = bx0 * p.ss + p.omin[2];
-        __syncthreads();
-        // F tile: 256 base pixels x FB channels; S patch.  Loads go out in batches of independent 16-byte
-        // vectors per thread before the LDS writes.
-        {
-            constexpr int VPP = FB * ESZ / 16;  // 16-byte vectors per pixel
-            constexpr int FU = VPP < 8 ? VPP : 8;
-            for (int base = tid; base < 256 * VPP; base += 256 * FU) {
-                uint4 v[FU];
 #pragma unroll
-                for (int u = 0; u < FU; ++u) {
-                    const int id = base + u * 256;
-                    const int pix = id / VPP, cv = id % VPP;
-                    const int tx = pix & mx, ty = (pix >> p.tlog[2]) & my, tz = pix >> (p.tlog[2] + p.tlog[1]);
-                    const int bz = bz0 + tz, by = by0 + ty, bx = bx0 + tx;
-                    v[u] = make_uint4(0u, 0u, 0u, 0u);
-                    if (bz < p.bd[0] && by < p.bd[1] && bx < p.bd[2]) {
-                        const size_t gp = ((size_t)(img * p.bd[0] + bz) * p.bd[1] + by) * p.bd[2] + bx;
-                        v[u] = *reinterpret_cast<const uint4*>(fsrc + (gp * fpitch + fcoff) * ESZ + cv * 16);
+        for (int u = 0; u < FVPP; ++u) {
+            const int id = tid + u * 256;
+            const int pix = id / FVPP, cv = id % FVPP;
+            const int tx = pix & mx, ty = (pix >> p.tlog[2]) & my, tz = pix >> (p.tlog[2] + p.tlog[1]);
+            const int bz = bz0 + tz, by = by0 + ty, bx = bx0 + tx;
+            fv[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (bz < p.bd[0] && by < p.bd[1] && bx < p.bd[2]) {
+                const size_t gp = ((size_t)(img * p.bd[0] + bz) * p.bd[1] + by) * p.bd[2] + bx;
+                fv[u] = *reinterpret_cast<const uint4*>(fsrc + (gp * fpitch + fcoff) * ESZ + cv * 16);
+            }
+        }
+        if (with_s) {
+#pragma unroll
+            for (int u = 0; u < SMAX; ++u) {
+                const int id = tid + u * 256;
+                sv[u] = make_uint4(0u, 0u, 0u, 0u);
+                if (id < stotal) {
+                    const int pix = id / SVPP, cv = id % SVPP;
+                    const int pz = fast_div(pix, p.mg_pd12); const int r = pix - pz * pd12;
+                    const int py = fast_div(r, p.mg_pd2); const int px = r - py * p.pd[2];
+                    const int iz = iz0 + pz, iy = iy0 + py, ix = ix0 + px;
+                    if ((unsigned)iz < (unsigned)p.sd[0] && (unsigned)iy < (unsigned)p.sd[1] &&
+                        (unsigned)ix < (unsigned)p.sd[2]) {
+                        const size_t gp = ((size_t)(img * p.sd[0] + iz) * p.sd[1] + iy) * p.sd[2] + ix;
+                        sv[u] = *reinterpret_cast<const uint4*>(p.s + (gp * p.s_pitch + p.s_coff + sb0) * ESZ + cv * 16);
                     }
-                }
-#pragma unroll
-                for (int u = 0; u < FU; ++u) {
-                    const int id = base + u * 256;
-                    *reinterpret_cast<uint4*>(smF + (id / VPP) * FPITCH + (id % VPP) * 16) = v[u];
                 }
             }
         }
-        {
-            constexpr int VPP = SB * ESZ / 16;
-            constexpr int SU = 4;
-            const int total = PP * VPP;
-            for (int base = tid; base < total; base += 256 * SU) {
-                uint4 v[SU];
+    };
+    auto store_tile = [&](bool with_s) {
 #pragma unroll
-                for (int u = 0; u < SU; ++u) {
-                    const int id = base + u * 256;
-                    v[u] = make_uint4(0u, 0u, 0u, 0u);
-                    if (id < total) {
-                        const int pix = id / VPP, cv = id % VPP;
-                        const int pz = fast_div(pix, p.mg_pd12); const int r = pix - pz * pd12;
-                        const int py = fast_div(r, p.mg_pd2); const int px = r - py * p.pd[2];
-                        const int iz = iz0 + pz, iy = iy0 + py, ix = ix0 + px;
-                        if ((unsigned)iz < (unsigned)p.sd[0] && (unsigned)iy < (unsigned)p.sd[1] &&
-                            (unsigned)ix < (unsigned)p.sd[2]) {
-                            const size_t gp = ((size_t)(img * p.sd[0] + iz) * p.sd[1] + iy) * p.sd[2] + ix;
-                            v[u] = *reinterpret_cast<const uint4*>(p.s + (gp * p.s_pitch + p.s_coff + sb0) * ESZ + cv * 16);
-                        }
-                    }
-                }
+        for (int u = 0; u < FVPP; ++u) {
+            const int id = tid + u * 256;
+            *reinterpret_cast<uint4*>(smF + (id / FVPP) * FPITCH + (id % FVPP) * 16) = fv[u];
+        }
+        if (with_s) {
 #pragma unroll
-                for (int u = 0; u < SU; ++u) {
-                    const int id = base + u * 256;
-                    if (id < total) *reinterpret_cast<uint4*>(smS + (id / VPP) * SPITCH + (id % VPP) * 16) = v[u];
-                }
+            for (int u = 0; u < SMAX; ++u) {
+                const int id = tid + u * 256;
+                if (id < stotal) *reinterpret_cast<uint4*>(smS + (id / SVPP) * SPITCH + (id % SVPP) * 16) = sv[u];
             }
         }
+    };
+    // S patch staged straight to LDS in batches (patches too large for the register budget)
+    auto stage_s_direct = [&](int tile) {
+        const int img = tile / tiles_per_img;
+        int tr = tile - img * tiles_per_img;
+        const int txi = tr % p.ntile[2]; tr /= p.ntile[2];
+        const int tyi = tr % p.ntile[1]; const int tzi = tr / p.ntile[1];
+        const int iz0 = (tzi << p.tlog[0]) * p.ss + p.omin[0] + p.tg_zoff[tgi], iy0 = (tyi << p.tlog[1]) * p.ss + p.omin[1],
+                  ix0 = (txi << p.tlog[2]) * p.ss + p.omin[2];
+        constexpr int SU = 4;
+        for (int base = tid; base < stotal; base += 256 * SU) {
+            uint4 v[SU];
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                const int id = base + u * 256;
+                v[u] = make_uint4(0u, 0u, 0u, 0u);
+                if (id < stotal) {
+                    const int pix = id / SVPP, cv = id % SVPP;
+                    const int pz = fast_div(pix, p.mg_pd12); const int r = pix - pz * pd12;
+                    const int py = fast_div(r, p.mg_pd2); const int px = r - py * p.pd[2];
+                    const int iz = iz0 + pz, iy = iy0 + py, ix = ix0 + px;
+                    if ((unsigned)iz < (unsigned)p.sd[0] && (unsigned)iy < (unsigned)p.sd[1] &&
+                        (unsigned)ix < (unsigned)p.sd[2]) {
+                        const size_t gp = ((size_t)(img * p.sd[0] + iz) * p.sd[1] + iy) * p.sd[2] + ix;
+                        v[u] = *reinterpret_cast<const uint4*>(p.s + (gp * p.s_pitch + p.s_coff + sb0) * ESZ + cv * 16);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                const int id = base + u * 256;
+                if (id < stotal) *reinterpret_cast<uint4*>(smS + (id / SVPP) * SPITCH + (id % SVPP) * 16) = v[u];
+            }
+        }
+    };
+    const bool pf_s = nsv <= SMAX;
+    if (blockIdx.x < p.tiles_total) load_tile(blockIdx.x, pf_s);
+    for (int tile = blockIdx.x; tile < p.tiles_total; tile += p.nsplit) {
+        __syncthreads();                       // the previous tile has been consumed
+        store_tile(pf_s);
+        if (!pf_s) stage_s_direct(tile);
         __syncthreads();
+        if (tile + p.nsplit < p.tiles_total) load_tile(tile + p.nsplit, pf_s);   // in flight during the multiply
         for (int ks = wk; ks < 8; ks += WK) {
             if (TR::ESZ == 2) {
                 // bf16: K-step = 32 pixels; lane group g covers pixels 8g..8g+7 via two transposed LDS reads

@@ -168,13 +168,21 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const NormParams p
     da = wave_sum(da);
     if ((threadIdx.x & 63) == 0) red_da[threadIdx.x >> 6] = da;
     __syncthreads();
+    // fixed-shape tree over the pixel rows of the workgroup: row r takes row r + half
+    for (int n = l.rows; n > 1;) {
+        const int half = (n + 1) >> 1;
+        if (l.prow + half < n) {
+#pragma unroll
+            for (int e = 0; e < 2 * VEC; ++e) part[threadIdx.x * 2 * VEC + e] += part[(threadIdx.x + half * cv_n) * 2 * VEC + e];
+        }
+        __syncthreads();
+        n = half;
+    }
     const int slot = blockIdx.x % MI_NSLOT;
     for (int i = threadIdx.x; i < 2 * p.c; i += 256) {
         const int ch = i >> 1, k = i & 1;
         const int ccv = ch / VEC, e = ch - ccv * VEC;
-        float a = 0.f;
-        for (int r = 0; r < l.rows; ++r) a += part[(r * cv_n + ccv) * 2 * VEC + k * VEC + e];
-        atomicAdd(&p.bstats[(((size_t)img * MI_NSLOT + slot) * p.c) * 2 + i], (double)a);
+        atomicAdd(&p.bstats[(((size_t)img * MI_NSLOT + slot) * p.c) * 2 + i], (double)part[ccv * 2 * VEC + k * VEC + e]);
     }
     if (threadIdx.x == 0 && p.dalpha) {
         const float v = ((red_da[0] + red_da[1]) + red_da[2]) + red_da[3];
@@ -370,8 +378,10 @@ int norm_bwd_reduce_blocks(int npix, int c) {
         return g < 1 ? 1 : g > 128 ? 128 : g;
     }
     // one count for both dtypes (the caller sizes the slope-gradient slots from it): 32 sweeps of an fp32
-    // workgroup = 16 sweeps of a bf16 one
-    return norm_blocks(npix, c, 4, 32, 256);
+    // workgroup (16 of a bf16 one), but at least 16 workgroups per image while 4 sweeps remain
+    const int g = norm_blocks(npix, c, 4, 32, 256);
+    const int gmin = norm_blocks(npix, c, 4, 4, 16);
+    return g > gmin ? g : gmin;
 }
 
 // dtype: 0 fp32, 1 bf16.  c == 1 selects the planar fp32 kernels (pitch must be 1, dtype 0).
