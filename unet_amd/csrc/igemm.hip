@@ -294,11 +294,11 @@ __device__ __forceinline__ float row_sum16(float v) {
 // one LDS base and one output offset; a workgroup walks `tpw` consecutive tiles of one image row, keeps
 // its staging descriptors in registers, stages the weight image once when a single staging covers it
 // and reduces the statistics partials once.
-template <class TR, int CPS, int NFRAG, int KS>
+template <class TR, int CPS, int NFRAG, int KS, int SA>
 __global__ __launch_bounds__(256) void igemm2d_kernel(const IgemmParams p) {
     constexpr int ESZ = TR::ESZ;
     constexpr int KCB = CPS * 16, KCE = KCB / ESZ, PITCH = KCB + 16, NT = NFRAG * 16;
-    constexpr int PD = KS == 3 ? 18 : KS == 2 ? 17 : 16;
+    constexpr int PD = KS == 3 ? 15 * SA + 3 : KS == 2 ? 17 : 16;
     constexpr int PP = PD * PD, TOTAL = PP * CPS, NSLOT = (TOTAL + 255) / 256;
     constexpr int MAXTAP = KS == 3 ? 9 : KS == 2 ? 4 : 1;
     constexpr int TAPPAD = (CPS == 2) ? ((MAXTAP + 1) & ~1) : MAXTAP;
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void igemm2d_kernel(const IgemmParams p) {
     const bool w_once = p.K <= KCE;
 
     // lane constants: tile pixel (ty = 4 wave + mf, tx = lr)
-    const int a_base0 = ((wave * 4) * PD + lr) * PITCH;
+    const int a_base0 = ((wave * 4 * SA) * PD + lr * SA) * PITCH;
     const int rel0 = (wave * 4 * p.so) * p.od[2] + lr * p.so;
     const int rel_step = p.so * p.od[2];
     const int cc_s = tid % CPS;
@@ -371,10 +371,10 @@ __global__ __launch_bounds__(256) void igemm2d_kernel(const IgemmParams p) {
         for (int j = 0; j < 4; ++j) { s1[nf][j] = 0.f; s2[nf][j] = 0.f; }
 
     const int by0 = tyi << 4;
-    const int iy0 = by0 + p.omin[1];
+    const int iy0 = by0 * SA + p.omin[1];
     for (int ti = 0; ti < p.tpw; ++ti) {
         const int bx0 = (txw * p.tpw + ti) << 4;
-        const int ix0 = bx0 + p.omin[2];
+        const int ix0 = bx0 * SA + p.omin[2];
         const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + PD <= H && ix0 + PD <= W;
         const long long org = ((long long)img * H + iy0) * W + ix0;   // patch origin pixel (may lie outside)
 
@@ -393,20 +393,24 @@ __global__ __launch_bounds__(256) void igemm2d_kernel(const IgemmParams p) {
             const char* pb = src + org * spb + scoff * ESZ + cc_s * 16;   // only dereferenced inside the tensor
             __syncthreads();
             {
-                uint4 v[NSLOT];
+                constexpr int SBATCH = 6;
 #pragma unroll
-                for (int u = 0; u < NSLOT; ++u) {
-                    v[u] = make_uint4(0u, 0u, 0u, 0u);
-                    bool ok = s_co[u] >= 0;
-                    if (!interior && ok) {
-                        const int iy = iy0 + (s_co[u] >> 10), ix = ix0 + (s_co[u] & 1023);
-                        ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                for (int u0 = 0; u0 < NSLOT; u0 += SBATCH) {
+                    uint4 v[SBATCH];
+#pragma unroll
+                    for (int u = u0; u < u0 + SBATCH && u < NSLOT; ++u) {
+                        v[u - u0] = make_uint4(0u, 0u, 0u, 0u);
+                        bool ok = s_co[u] >= 0;
+                        if (!interior && ok) {
+                            const int iy = iy0 + (s_co[u] >> 10), ix = ix0 + (s_co[u] & 1023);
+                            ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                        }
+                        if (ok) v[u - u0] = *reinterpret_cast<const uint4*>(pb + (size_t)__umul24(s_pl[u], spb));
                     }
-                    if (ok) v[u] = *reinterpret_cast<const uint4*>(pb + (size_t)__umul24(s_pl[u], spb));
-                }
 #pragma unroll
-                for (int u = 0; u < NSLOT; ++u)
-                    if (s_co[u] >= 0) *reinterpret_cast<uint4*>(smA + lo0 + u * RSTEP) = v[u];
+                    for (int u = u0; u < u0 + SBATCH && u < NSLOT; ++u)
+                        if (s_co[u] >= 0) *reinterpret_cast<uint4*>(smA + lo0 + u * RSTEP) = v[u - u0];
+                }
             }
             if (!w_once) stage_weights(kc);
             __syncthreads();
@@ -425,7 +429,7 @@ __global__ __launch_bounds__(256) void igemm2d_kernel(const IgemmParams p) {
                 uint4 bfr[4], afr[NFRAG];
 #pragma unroll
                 for (int mf = 0; mf < 4; ++mf)
-                    bfr[mf] = *reinterpret_cast<const uint4*>(smA + a_base0 + mf * PD * PITCH + toff + cc * 16);
+                    bfr[mf] = *reinterpret_cast<const uint4*>(smA + a_base0 + mf * SA * PD * PITCH + toff + cc * 16);
 #pragma unroll
                 for (int nf = 0; nf < NFRAG; ++nf)
                     afr[nf] = *reinterpret_cast<const uint4*>(smW + ((tl * NT + nf * 16 + lr) * PITCH) + cc * 16);
@@ -938,20 +942,22 @@ int launch_igemm_t(const IgemmParams& pin, hipStream_t st) {
 
 // 2-D unit-stride specialisation: usable when the generic geometry chose a 16 x 16 tile on a 2-D tensor
 inline int igemm2d_ks(const IgemmParams& p) {
-    if (p.sa != 1 || p.id[0] != 1 || p.tlog[0] != 0 || p.tlog[1] != 4 || p.tlog[2] != 4 || p.pd[0] != 1) return 0;
+    if (p.id[0] != 1 || p.tlog[0] != 0 || p.tlog[1] != 4 || p.tlog[2] != 4 || p.pd[0] != 1) return 0;
     const int ntaps = p.phase_start[p.nphase];
+    if (p.sa == 2) return (p.nphase == 1 && p.so == 1 && ntaps == 9 && p.pd[1] == 33 && p.pd[2] == 33) ? 3 : 0;
+    if (p.sa != 1) return 0;
     if (p.nphase == 4 && p.so == 2 && p.pd[1] == 17 && p.pd[2] == 17 && ntaps == 9) return 2;
     if (p.nphase == 1 && p.so == 1 && ntaps == 9 && p.pd[1] == 18 && p.pd[2] == 18) return 3;
     if (p.nphase == 1 && p.so == 1 && ntaps == 1 && p.pd[1] == 16 && p.pd[2] == 16) return 1;
     return 0;
 }
 
-template <class TR, int CPS, int NFRAG, int KS>
+template <class TR, int CPS, int NFRAG, int KS, int SA>
 int launch_igemm2d_t(const IgemmParams& pin, hipStream_t st) {
     IgemmParams p = pin;
     if (!p.out1) p.out0_c = p.N;
     constexpr int PITCH = CPS * 16 + 16, NT = NFRAG * 16;
-    constexpr int PD = KS == 3 ? 18 : KS == 2 ? 17 : 16;
+    constexpr int PD = KS == 3 ? 15 * SA + 3 : KS == 2 ? 17 : 16;
     constexpr int MAXTAP = KS == 3 ? 9 : KS == 2 ? 4 : 1;
     constexpr int TAPPAD = (CPS == 2) ? ((MAXTAP + 1) & ~1) : MAXTAP;
     {
@@ -965,7 +971,7 @@ int launch_igemm2d_t(const IgemmParams& pin, hipStream_t st) {
     }
     size_t lds = (size_t)PD * PD * PITCH + (size_t)TAPPAD * NT * PITCH;
     if (lds < (size_t)NT * 2 * 4 * 4) lds = NT * 2 * 4 * 4;
-    auto kern = igemm2d_kernel<TR, CPS, NFRAG, KS>;
+    auto kern = igemm2d_kernel<TR, CPS, NFRAG, KS, SA>;
     if (int r = set_lds(kern, lds)) return r;
     dim3 grid(p.nb * p.ntile[1] * (p.ntile[2] / p.tpw), p.N / NT, p.nphase);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
@@ -1014,6 +1020,11 @@ void igemm_config(int dtype, const IgemmParams& p, int* cps, int* nfrag) {
     const int kce4 = 64 / esz;
     int c = (p.K % kce4 == 0 && (p.in0_c >= p.K || p.in0_c % kce4 == 0)) ? 4 : 2;
     int nf = (p.N % 64 == 0) ? 4 : (p.N % 32 == 0) ? 2 : 1;
+    if (!getenv("MI_NO_IGEMM2D") && igemm2d_ks(p) == 3 && p.sa == 2) {
+        // 33 x 33 patch: 32-byte chunks; with at most 64 output channels two 32-channel workgroups fit a CU
+        c = 2;
+        if (nf > 2 && p.N <= 64) nf = 2;
+    }
     if (c == 4 && igemm_lds_for(p, c, nf) > kLdsBudget) c = 2;
     while (nf > 1 && igemm_lds_for(p, c, nf) > kLdsBudget) nf >>= 1;
     *cps = c; *nfrag = nf;
@@ -1041,9 +1052,10 @@ int launch_igemm(int dtype, const IgemmParams& p, hipStream_t st) {
     const int ks = getenv("MI_NO_IGEMM2D") ? 0 : igemm2d_ks(p);
 #define IG_CASE(TRT, C, NF)                                                  \
     if (cps == C && nfrag == NF) {                                           \
-        if (ks == 3) return launch_igemm2d_t<TRT, C, NF, 3>(p, st);          \
-        if (ks == 2) return launch_igemm2d_t<TRT, C, NF, 2>(p, st);          \
-        if (ks == 1) return launch_igemm2d_t<TRT, C, NF, 1>(p, st);          \
+        if (ks == 3 && p.sa == 2 && C == 2) return launch_igemm2d_t<TRT, 2, NF, 3, 2>(p, st); \
+        if (ks == 3 && p.sa == 1) return launch_igemm2d_t<TRT, C, NF, 3, 1>(p, st); \
+        if (ks == 2) return launch_igemm2d_t<TRT, C, NF, 2, 1>(p, st);       \
+        if (ks == 1) return launch_igemm2d_t<TRT, C, NF, 1, 1>(p, st);       \
         return launch_igemm_t<TRT, C, NF>(p, st);                            \
     }
     if (dtype) {
