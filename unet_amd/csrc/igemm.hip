@@ -294,13 +294,17 @@ __device__ __forceinline__ float row_sum16(float v) {
 // one LDS base and one output offset; a workgroup walks `tpw` consecutive tiles of one image row, keeps
 // its staging descriptors in registers, stages the weight image once when a single staging covers it
 // and reduces the statistics partials once.
-template <class TR, int CPS, int NFRAG, int KS, int SA>
+template <class TR, int CPS, int NFRAG, int KS, int SA, bool PHL>
 __global__ __launch_bounds__(256) void igemm2d_kernel(const IgemmParams p) {
     constexpr int ESZ = TR::ESZ;
     constexpr int KCB = CPS * 16, KCE = KCB / ESZ, PITCH = KCB + 16, NT = NFRAG * 16;
     constexpr int PD = KS == 3 ? 15 * SA + 3 : KS == 2 ? 17 : 16;
     constexpr int PP = PD * PD, TOTAL = PP * CPS, NSLOT = (TOTAL + 255) / 256;
-    constexpr int MAXTAP = KS == 3 ? 9 : KS == 2 ? 4 : 1;
+    // PHL (KS = 2 only): one workgroup computes all four scatter phases from one staged patch
+    constexpr int NPH = PHL ? 4 : 1;
+    constexpr int MAXTAP = KS == 3 ? 9 : KS == 2 ? (PHL ? 9 : 4) : 1;
+    constexpr int PS[5] = {0, 1, 3, 5, 9};   // tap ranges of the four 2-D phases (even/even, x odd, y odd, both odd)
+    static_assert(!PHL || (KS == 2 && CPS == 4), "the phase loop needs the stride-2 scatter taps and 64-byte chunks");
     constexpr int TAPPAD = (CPS == 2) ? ((MAXTAP + 1) & ~1) : MAXTAP;
     constexpr int MAXW = (TAPPAD * NT * CPS + 255) / 256;
     constexpr int RSTEP = (256 / CPS) * PITCH;     // LDS bytes between two staging slots of a thread
@@ -318,9 +322,9 @@ __global__ __launch_bounds__(256) void igemm2d_kernel(const IgemmParams p) {
     const int img = b / p.ntile[1];
     const int slot = blockIdx.x % MI_NSLOT;
     const int n0 = blockIdx.y * NT;
-    const int ph = blockIdx.z;
+    const int ph = PHL ? 0 : blockIdx.z;
     const int H = p.id[1], W = p.id[2];
-    const int t_begin = p.phase_start[ph], ntap = p.phase_start[ph + 1] - t_begin;
+    const int t_begin = PHL ? 0 : p.phase_start[ph], ntap = PHL ? 9 : p.phase_start[ph + 1] - t_begin;
     const bool w_once = p.K <= KCE;
 
     // lane constants: tile pixel (ty = 4 wave + mf, tx = lr)
@@ -378,11 +382,13 @@ __global__ __launch_bounds__(256) void igemm2d_kernel(const IgemmParams p) {
         const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + PD <= H && ix0 + PD <= W;
         const long long org = ((long long)img * H + iy0) * W + ix0;   // patch origin pixel (may lie outside)
 
-        v4f acc[4][NFRAG];
+        v4f acc[NPH][4][NFRAG];
 #pragma unroll
-        for (int mf = 0; mf < 4; ++mf)
+        for (int q = 0; q < NPH; ++q)
 #pragma unroll
-            for (int nf = 0; nf < NFRAG; ++nf) acc[mf][nf] = v4f{0.f, 0.f, 0.f, 0.f};
+            for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+                for (int nf = 0; nf < NFRAG; ++nf) acc[q][mf][nf] = v4f{0.f, 0.f, 0.f, 0.f};
 
         for (int kc = 0; kc < p.K; kc += KCE) {
             const char* src;
@@ -414,35 +420,57 @@ __global__ __launch_bounds__(256) void igemm2d_kernel(const IgemmParams p) {
             }
             if (!w_once) stage_weights(kc);
             __syncthreads();
-            constexpr int NSTEP = (CPS == 4) ? MAXTAP : (MAXTAP + 1) / 2;
+            if (PHL) {
 #pragma unroll
-            for (int s = 0; s < NSTEP; ++s) {
-                int tl, cc, toff;
-                if (CPS == 4) {
-                    if (s >= ntap) break;
-                    tl = s; cc = g; toff = toffs[s];
-                } else {
-                    if (2 * s >= ntap) break;
-                    tl = 2 * s + (g >> 1); cc = g & 1;
-                    toff = (g >> 1) ? toffs[(2 * s + 1 < MAXTAP) ? 2 * s + 1 : 2 * s] : toffs[2 * s];
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int t = PS[q]; t < PS[q + 1]; ++t) {
+                        uint4 bfr[4], afr[NFRAG];
+#pragma unroll
+                        for (int mf = 0; mf < 4; ++mf)
+                            bfr[mf] = *reinterpret_cast<const uint4*>(smA + a_base0 + mf * SA * PD * PITCH + toffs[t] + g * 16);
+#pragma unroll
+                        for (int nf = 0; nf < NFRAG; ++nf)
+                            afr[nf] = *reinterpret_cast<const uint4*>(smW + ((t * NT + nf * 16 + lr) * PITCH) + g * 16);
+#pragma unroll
+                        for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+                            for (int nf = 0; nf < NFRAG; ++nf) acc[q][mf][nf] = mma16<TR>(afr[nf], bfr[mf], acc[q][mf][nf]);
+                    }
+            } else {
+                constexpr int NSTEP = (CPS == 4) ? MAXTAP : (MAXTAP + 1) / 2;
+#pragma unroll
+                for (int s = 0; s < NSTEP; ++s) {
+                    int tl, cc, toff;
+                    if (CPS == 4) {
+                        if (s >= ntap) break;
+                        tl = s; cc = g; toff = toffs[s];
+                    } else {
+                        if (2 * s >= ntap) break;
+                        tl = 2 * s + (g >> 1); cc = g & 1;
+                        toff = (g >> 1) ? toffs[(2 * s + 1 < MAXTAP) ? 2 * s + 1 : 2 * s] : toffs[2 * s];
+                    }
+                    uint4 bfr[4], afr[NFRAG];
+#pragma unroll
+                    for (int mf = 0; mf < 4; ++mf)
+                        bfr[mf] = *reinterpret_cast<const uint4*>(smA + a_base0 + mf * SA * PD * PITCH + toff + cc * 16);
+#pragma unroll
+                    for (int nf = 0; nf < NFRAG; ++nf)
+                        afr[nf] = *reinterpret_cast<const uint4*>(smW + ((tl * NT + nf * 16 + lr) * PITCH) + cc * 16);
+#pragma unroll
+                    for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+                        for (int nf = 0; nf < NFRAG; ++nf) acc[0][mf][nf] = mma16<TR>(afr[nf], bfr[mf], acc[0][mf][nf]);
                 }
-                uint4 bfr[4], afr[NFRAG];
-#pragma unroll
-                for (int mf = 0; mf < 4; ++mf)
-                    bfr[mf] = *reinterpret_cast<const uint4*>(smA + a_base0 + mf * SA * PD * PITCH + toff + cc * 16);
-#pragma unroll
-                for (int nf = 0; nf < NFRAG; ++nf)
-                    afr[nf] = *reinterpret_cast<const uint4*>(smW + ((tl * NT + nf * 16 + lr) * PITCH) + cc * 16);
-#pragma unroll
-                for (int mf = 0; mf < 4; ++mf)
-#pragma unroll
-                    for (int nf = 0; nf < NFRAG; ++nf) acc[mf][nf] = mma16<TR>(afr[nf], bfr[mf], acc[mf][nf]);
             }
         }
 
         // ---- tile epilogue ---------------------------------------------------------------------
         const bool full = by0 + 16 <= p.bd[1] && bx0 + 16 <= p.bd[2];
-        const int base_pix = (img * p.od[1] + by0 * p.so + p.phase_off[ph][1]) * p.od[2] + bx0 * p.so + p.phase_off[ph][2];
+#pragma unroll
+        for (int q = 0; q < NPH; ++q) {
+        const int phx = PHL ? q : ph;
+        const int base_pix = (img * p.od[1] + by0 * p.so + p.phase_off[phx][1]) * p.od[2] + bx0 * p.so + p.phase_off[phx][2];
 #pragma unroll
         for (int mf = 0; mf < 4; ++mf) {
             const bool valid = full || (by0 + wave * 4 + mf < p.bd[1] && bx0 + lr < p.bd[2]);
@@ -451,7 +479,7 @@ __global__ __launch_bounds__(256) void igemm2d_kernel(const IgemmParams p) {
                 for (int nf = 0; nf < NFRAG; ++nf)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float v = valid ? acc[mf][nf][j] : 0.f;
+                        const float v = valid ? acc[q][mf][nf][j] : 0.f;
                         s1[nf][j] += v; s2[nf][j] += v * v;
                     }
             }
@@ -461,7 +489,7 @@ __global__ __launch_bounds__(256) void igemm2d_kernel(const IgemmParams p) {
                     const int ch = n0 + 4 * g;
                     float v[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = acc[mf][0][j];
+                    for (int j = 0; j < 4; ++j) v[j] = acc[q][mf][0][j];
                     if (p.bias && ch >= p.bias_c0) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] += p.bias[ch - p.bias_c0 + j];
@@ -481,7 +509,7 @@ __global__ __launch_bounds__(256) void igemm2d_kernel(const IgemmParams p) {
                         const int ch = n0 + 32 * pf + 8 * g;
                         float v[8];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) { v[j] = acc[mf][2 * pf][j]; v[4 + j] = acc[mf][2 * pf + 1][j]; }
+                        for (int j = 0; j < 4; ++j) { v[j] = acc[q][mf][2 * pf][j]; v[4 + j] = acc[q][mf][2 * pf + 1][j]; }
                         if (p.bias && ch >= p.bias_c0) {
 #pragma unroll
                             for (int j = 0; j < 8; ++j) v[j] += p.bias[ch - p.bias_c0 + j];
@@ -498,6 +526,7 @@ __global__ __launch_bounds__(256) void igemm2d_kernel(const IgemmParams p) {
                     }
                 }
             }
+        }
         }
     }
     if (do_stats) {
@@ -952,17 +981,18 @@ inline int igemm2d_ks(const IgemmParams& p) {
     return 0;
 }
 
-template <class TR, int CPS, int NFRAG, int KS, int SA>
+template <class TR, int CPS, int NFRAG, int KS, int SA, bool PHL = false>
 int launch_igemm2d_t(const IgemmParams& pin, hipStream_t st) {
     IgemmParams p = pin;
     if (!p.out1) p.out0_c = p.N;
     constexpr int PITCH = CPS * 16 + 16, NT = NFRAG * 16;
     constexpr int PD = KS == 3 ? 15 * SA + 3 : KS == 2 ? 17 : 16;
-    constexpr int MAXTAP = KS == 3 ? 9 : KS == 2 ? 4 : 1;
+    constexpr int MAXTAP = KS == 3 ? 9 : KS == 2 ? (PHL ? 9 : 4) : 1;
     constexpr int TAPPAD = (CPS == 2) ? ((MAXTAP + 1) & ~1) : MAXTAP;
+    const int nz = PHL ? 1 : p.nphase;
     {
         // tiles per workgroup (consecutive along x): about eight workgroups per CU stay in flight
-        const long long wgs = (long long)p.nb * p.ntile[1] * p.ntile[2] * (p.N / NT) * p.nphase;
+        const long long wgs = (long long)p.nb * p.ntile[1] * p.ntile[2] * (p.N / NT) * nz;
         int want = (int)(wgs / 2048);
         if (want > 8) want = 8;
         int tpw = 1;
@@ -971,9 +1001,9 @@ int launch_igemm2d_t(const IgemmParams& pin, hipStream_t st) {
     }
     size_t lds = (size_t)PD * PD * PITCH + (size_t)TAPPAD * NT * PITCH;
     if (lds < (size_t)NT * 2 * 4 * 4) lds = NT * 2 * 4 * 4;
-    auto kern = igemm2d_kernel<TR, CPS, NFRAG, KS, SA>;
+    auto kern = igemm2d_kernel<TR, CPS, NFRAG, KS, SA, PHL>;
     if (int r = set_lds(kern, lds)) return r;
-    dim3 grid(p.nb * p.ntile[1] * (p.ntile[2] / p.tpw), p.N / NT, p.nphase);
+    dim3 grid(p.nb * p.ntile[1] * (p.ntile[2] / p.tpw), p.N / NT, nz);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { mi_set_error(std::string("igemm2d launch: ") + hipGetErrorString(e)); return -2; }
@@ -1050,10 +1080,13 @@ int launch_igemm(int dtype, const IgemmParams& p, hipStream_t st) {
     MI_CHECK((long long)p.nb * p.od[0] * p.od[1] * p.od[2] < (1ll << 31) && (long long)p.nb * p.id[0] * p.id[1] * p.id[2] < (1ll << 31),
              "tensor has too many pixels for 32-bit pixel indices");
     const int ks = getenv("MI_NO_IGEMM2D") ? 0 : igemm2d_ks(p);
+    int phl_max = 2;   // widest channel tile (in 16-channel fragments) that loops over the scatter phases in one workgroup
+    if (const char* e = getenv("MI_PHL_MAX")) phl_max = atoi(e);
 #define IG_CASE(TRT, C, NF)                                                  \
     if (cps == C && nfrag == NF) {                                           \
         if (ks == 3 && p.sa == 2 && C == 2) return launch_igemm2d_t<TRT, 2, NF, 3, 2>(p, st); \
         if (ks == 3 && p.sa == 1) return launch_igemm2d_t<TRT, C, NF, 3, 1>(p, st); \
+        if (ks == 2 && C == 4 && NF <= phl_max) return launch_igemm2d_t<TRT, 4, (NF <= 2 ? NF : 1), 2, 1, true>(p, st); \
         if (ks == 2) return launch_igemm2d_t<TRT, C, NF, 2, 1>(p, st);       \
         if (ks == 1) return launch_igemm2d_t<TRT, C, NF, 1, 1>(p, st);       \
         return launch_igemm_t<TRT, C, NF>(p, st);                            \
