@@ -111,6 +111,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="all-reduce after the whole backward")
+    ap.add_argument("--mode", default="train", choices=("train", "infer"),
+                    help="infer: sliding-window evaluation of --batch slices per GPU and step (roi 256, 9 windows per slice)")
+    ap.add_argument("--roi", type=int, default=256)
+    ap.add_argument("--sw-batch", type=int, default=36, help="windows per model call in --mode infer")
     args = ap.parse_args()
 
     import unet_amd
@@ -142,6 +146,40 @@ def main():
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
+
+    if args.mode == "infer":
+        # reference/train.py:128-153 on synthetic slices: sliding-window forward, sigmoid + threshold, Dice per slice
+        from unet_amd.evaluator import VolumeEvaluator
+        model.eval()
+        ev = VolumeEvaluator(model, (args.roi,) * args.dims, sw_batch_size=args.sw_batch, slices_per_call=max(1, args.sw_batch // 9))
+        for _ in range(args.warmup):
+            ev.slice_dice(x, t)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            d = ev.slice_dice(x, t)
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        nwin = len(unet_amd.window_starts([max(args.size, args.roi)] * args.dims, [args.roi] * args.dims, 0.25))
+        if rank == 0:
+            print(json.dumps({
+                "metric": "inference slices/sec (whole node), sliding window", "value": round(world * args.batch * args.steps / elapsed, 2),
+                "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                "config": {"workload": f"{args.dims}D U-Net ch {'-'.join(map(str, channels))}, {args.batch} slices of "
+                                       f"{'x'.join(map(str, sp))} per GPU and step, roi {args.roi}, overlap 0.25 ({nwin} windows per "
+                                       f"slice), {args.sw_batch} windows per model call, hard Dice per slice (BASELINE.json configs[4] shape)",
+                           "parallelism": f"slices sharded over {world} GPU(s)"},
+                "mean_dice": round(float(torch.nan_to_num(d).mean()), 5)}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     for _ in range(args.warmup):
         trainer.step(x, t)

@@ -9,6 +9,7 @@ from .inferers import sliding_window_inference, window_starts, shard_range  # no
 from .transforms import Activations, AsDiscrete, Compose, decollate_batch  # noqa: F401
 from .optim import AdamW  # noqa: F401
 from .trainer import Trainer  # noqa: F401
+from .evaluator import VolumeEvaluator  # noqa: F401
 from .utils import set_determinism, checkpoint_name, save_checkpoint, per_volume_dice, volume_id  # noqa: F401
 
 __version__ = "0.1.0"
