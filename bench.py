@@ -111,7 +111,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="all-reduce after the whole backward")
-    ap.add_argument("--mode", default="train", choices=("train", "infer"),
+    ap.add_argument("--mode", default="train", choices=("train", "infer", "pipeline"),
                     help="infer: sliding-window evaluation of --batch slices per GPU and step (roi 256, 9 windows per slice)")
     ap.add_argument("--roi", type=int, default=256)
     ap.add_argument("--sw-batch", type=int, default=36, help="windows per model call in --mode infer")
@@ -146,6 +146,33 @@ def main():
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
+
+    if args.mode == "pipeline":
+        # reference/unetDataset.py:68-93 on synthetic int16 CT-like slices resident in HBM: 4 crops of 256^2 per slice
+        pipe = unet_amd.SliceCropPipeline()
+        g = torch.Generator().manual_seed(7 + rank)
+        raw = (torch.rand(args.batch, args.size, args.size, generator=g) * 900 - 400).to(torch.int16).to(dev)
+        lab = (t[:, 0] > 0).to(torch.uint8).contiguous()
+        for _ in range(args.warmup):
+            pipe(raw, lab)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ci, cl = pipe(raw, lab)
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        if rank == 0:
+            ncrop = world * args.batch * pipe.num_samples * args.steps
+            print(json.dumps({
+                "metric": "training crops/sec (whole node), GPU input pipeline", "value": round(ncrop / elapsed, 1), "unit": "crops/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int16->f32", "data": "synthetic",
+                "config": {"workload": f"{args.batch} int16 slices of {args.size}x{args.size} per GPU and step -> {pipe.num_samples} crops of "
+                                       f"{pipe.roi}x{pipe.roi} each: intensity window, foreground box, pad, pos/neg crop, rot90"}}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     if args.mode == "infer":
         # reference/train.py:128-153 on synthetic slices: sliding-window forward, sigmoid + threshold, Dice per slice

@@ -136,6 +136,27 @@ int mi_sw_blend(const float* win_out, float* out, const int32_t* starts, int nwi
                 const int32_t roi[3], const int32_t pad_lo[3], void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * GPU-resident input pipeline of the 2-D training crops.  Replaces, on slices already in HBM, the
+ * arithmetic of ScaleIntensityRanged, CropForegroundd, SpatialPadd, RandCropByPosNegLabeld and
+ * RandRotate90d (reference/unetDataset.py:68-93); the random numbers are the caller's.
+ * Slices are planar [S][H][W]; image dtype 0 fp32 | 1 int16; label dtype as above.
+ * ------------------------------------------------------------------------------------------ */
+/* bbox[s] = {y0, y1, x0, x1}, half open, of the pixels with img > thr (the whole slice when there is none) */
+int mi_fg_bbox(const void* img, int img_dtype, float thr, int ns, int H, int W, int32_t* bbox, void* stream);
+/* centers[b] = (y, x), relative to the bounding box of slice sample_slice[b], of the floor(u[b][1] * n)-th
+ * pixel (row-major) of the class chosen by u[b][0] < pos_ratio: foreground = label > 0, background =
+ * label <= 0 and img > bg_thr */
+int mi_pick_centers(const void* img, int img_dtype, const void* lbl, int lbl_dtype, float bg_thr, const int32_t* bbox, int H,
+                    int W, const int32_t* sample_slice, const float* u, float pos_ratio, int nsamp, int32_t* centers,
+                    void* stream);
+/* desc[b] = {slice, oy, ox, k}: crop origin in slice coordinates (outside the bounding box = zero padding)
+ * and the number of counter-clockwise quarter turns; image values become
+ * clip((v - a_min) / (a_max - a_min) * (b_max - b_min) + b_min) */
+int mi_crop_scale_rot(const void* img, int img_dtype, const void* lbl, int lbl_dtype, int H, int W, const int32_t* desc,
+                      const int32_t* bbox, int nsamp, float a_min, float a_max, float b_min, float b_max, int clip, int ch,
+                      int cw, float* out_img, float* out_lbl, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Single operators (the engine is built from these; exported for operator-level parity tests
  * and for callers that assemble other networks).
  * ------------------------------------------------------------------------------------------ */

@@ -10,6 +10,7 @@ from .transforms import Activations, AsDiscrete, Compose, decollate_batch  # noq
 from .optim import AdamW  # noqa: F401
 from .trainer import Trainer  # noqa: F401
 from .evaluator import VolumeEvaluator  # noqa: F401
+from .pipeline import SliceCropPipeline  # noqa: F401
 from .utils import set_determinism, checkpoint_name, save_checkpoint, per_volume_dice, volume_id  # noqa: F401
 
 __version__ = "0.1.0"

@@ -85,6 +85,10 @@ PROTOTYPES = {
                                 C.c_int64, C.c_float, _P]),
     "mi_sw_gather": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _I3, _I3, _I3, C.c_float, _P]),
     "mi_sw_blend": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _I3, _I3, _I3, _P]),
+    "mi_fg_bbox": (C.c_int, [_P, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "mi_pick_centers": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_float, _P, C.c_int, C.c_int, _P, _P, C.c_float, C.c_int, _P, _P]),
+    "mi_crop_scale_rot": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_float, C.c_float,
+                                    C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "mi_conv_packed_bytes": (C.c_size_t, [C.POINTER(MiConvDesc)]),
     "mi_conv_pack": (C.c_int, [C.POINTER(MiConvDesc), C.c_int, _P, _P, _P]),
     "mi_conv_forward": (C.c_int, [C.POINTER(MiConvDesc), C.POINTER(MiTensor), _P, _P, C.POINTER(MiTensor),
