@@ -32,6 +32,7 @@ class Trainer:
         import torch.distributed as dist
 
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
 
     def _buffers(self, x):
         key = (tuple(x.shape), x.device)
@@ -83,7 +84,8 @@ class Trainer:
             self._loss_accum = torch.zeros(1, dtype=torch.float32, device=dev)
             self._reducer = BucketedAllReduce(self._grad, model.gradient_buckets(), self.group) if self.world > 1 else None
         st = _lib.current_stream(dev)
-        seed = model._next_seed()
+        # every rank draws its own dropout masks
+        seed = (model._next_seed() + 0x9E3779B97F4A7C15 * self.rank) & 0xFFFFFFFFFFFFFFFF
         nb, npix = x.shape[0], x[0].numel()
         L = self.loss
         plan.forward(flat, x, b["logits"], b["ws"], True, seed)
