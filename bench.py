@@ -279,7 +279,19 @@ def main():
         else:
             roof = {"bound": "hbm", "achieved": round(dom["bytes"] / sec / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s"}
         roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
+        # HBM bytes per launch of this kernel from the committed counter passes (FETCH_SIZE x2 + WRITE_SIZE), if any
         roof["traffic"] = None
+        try:
+            import glob
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
+            if files and args.batch == 32 and args.size == 512 and args.dims == 2 and args.dtype == "bf16":
+                tk = json.load(open(files[-1]))["kernels"].get(dom_name)
+                if tk:
+                    roof["traffic"] = tk["bytes_per_launch"]
+                    roof["traffic_source"] = os.path.basename(files[-1])
+        except (OSError, ValueError, KeyError):
+            pass
+        roof["algorithmic_bytes_per_launch"] = round(dom["bytes"] / max(1, dom["launches"]))
         roof["kernel"] = dom_name
         roof["avg_launch_us"] = round(1e3 * dom["ms"] / dom["launches"], 2)
         roof["launches_per_step"] = round(dom["launches"] / nprof, 1)

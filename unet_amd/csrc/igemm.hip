@@ -1057,6 +1057,13 @@ void igemm_config(int dtype, const IgemmParams& p, int* cps, int* nfrag) {
     }
     if (c == 4 && igemm_lds_for(p, c, nf) > kLdsBudget) c = 2;
     while (nf > 1 && igemm_lds_for(p, c, nf) > kLdsBudget) nf >>= 1;
+    {
+        // small problems: narrower channel tiles until there is about one workgroup per CU
+        int min_wgs = 256;
+        if (const char* e = getenv("MI_IGEMM_MIN_WGS")) min_wgs = atoi(e);
+        const long long tiles = (long long)p.nb * p.ntile[0] * p.ntile[1] * p.ntile[2] * p.nphase;
+        while (nf > 1 && tiles * (p.N / (16 * nf)) < min_wgs) nf >>= 1;
+    }
     *cps = c; *nfrag = nf;
 }
 
