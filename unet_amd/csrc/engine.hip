@@ -115,6 +115,12 @@ struct mi_unet {
     char* cached_reduce_bases[2] = {nullptr, nullptr};
     double flops_fwd = 0, flops_bwd = 0;
     int n_fwd_packs = 0;
+    // side stream for the weight-gradient launches of the backward pass (they depend only on tensors that are
+    // final when they are issued and are joined in front of each bucket's slab reduction)
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> side_ev;      // one "inputs ready" event per weight-gradient step, then one join event
+    hipEvent_t join_ev = nullptr;
+    int use_side = -1;                    // -1: undecided, 0: off, 1: on
     // profiling
     bool prof = false;
     std::vector<ProfEvent> events;
@@ -951,8 +957,24 @@ int run_step(mi_unet& u, Step& s, char* const* bases, int training, uint64_t see
     return -1;
 }
 
+bool is_wgrad_kind(int kind) { return kind == K_WGRAD || kind == K_C1_WGRAD || kind == K_STENCIL_WGRAD; }
+
 int run_list(mi_unet& u, std::vector<Step>& list, int backward, int bucket, char* const* bases, int training, uint64_t seed,
              hipStream_t st) {
+    // weight gradients run on a second stream next to the data-gradient chain; timing runs stay on one stream
+    bool side = false;
+    if (backward && !u.prof) {
+        if (u.use_side < 0) {
+            u.use_side = getenv("MI_NO_SIDE_STREAM") ? 0 : 1;
+            if (u.use_side) {
+                if (hipStreamCreateWithFlags(&u.side, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); u.use_side = 0; }
+                else if (hipEventCreateWithFlags(&u.join_ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); u.use_side = 0; }
+            }
+        }
+        side = u.use_side == 1;
+    }
+    bool pending = false;
+    size_t nside = 0;
     for (size_t i = 0; i < list.size(); ++i) {
         Step& s = list[i];
         if (bucket >= 0 && s.bucket != bucket) continue;
@@ -961,12 +983,34 @@ int run_list(mi_unet& u, std::vector<Step>& list, int backward, int bucket, char
             MI_HIP(hipEventCreate(&ev.a)); MI_HIP(hipEventCreate(&ev.b));
             MI_HIP(hipEventRecord(ev.a, st));
         }
-        if (int r = run_step(u, s, bases, training, seed, st)) return r;
+        if (side && is_wgrad_kind(s.kind)) {
+            if (nside >= u.side_ev.size()) {
+                hipEvent_t e;
+                MI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                u.side_ev.push_back(e);
+            }
+            hipEvent_t ready = u.side_ev[nside++];
+            MI_HIP(hipEventRecord(ready, st));
+            MI_HIP(hipStreamWaitEvent(u.side, ready, 0));
+            if (int r = run_step(u, s, bases, training, seed, u.side)) return r;
+            pending = true;
+        } else {
+            if (pending && s.kind == K_REDUCE) {
+                MI_HIP(hipEventRecord(u.join_ev, u.side));
+                MI_HIP(hipStreamWaitEvent(st, u.join_ev, 0));
+                pending = false;
+            }
+            if (int r = run_step(u, s, bases, training, seed, st)) return r;
+        }
         if (u.prof) {
             MI_HIP(hipEventRecord(ev.b, st));
             ev.backward = backward; ev.step = (int)i;
             u.events.push_back(ev);
         }
+    }
+    if (pending) {   // a list that does not end in a reduction: join anyway
+        MI_HIP(hipEventRecord(u.join_ev, u.side));
+        MI_HIP(hipStreamWaitEvent(st, u.join_ev, 0));
     }
     return 0;
 }
@@ -1017,6 +1061,9 @@ int mi_unet_create(const mi_unet_cfg* cfg, mi_unet** out) {
 void mi_unet_destroy(mi_unet* u) {
     if (!u) return;
     for (ProfEvent& e : u->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (hipEvent_t e : u->side_ev) (void)hipEventDestroy(e);
+    if (u->join_ev) (void)hipEventDestroy(u->join_ev);
+    if (u->side) (void)hipStreamDestroy(u->side);
     delete u;
 }
 
