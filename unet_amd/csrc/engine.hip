@@ -961,9 +961,11 @@ bool is_wgrad_kind(int kind) { return kind == K_WGRAD || kind == K_C1_WGRAD || k
 
 int run_list(mi_unet& u, std::vector<Step>& list, int backward, int bucket, char* const* bases, int training, uint64_t seed,
              hipStream_t st) {
-    // weight gradients run on a second stream next to the data-gradient chain; timing runs stay on one stream
+    // A second stream runs work that is off the critical chain: in the backward pass the weight gradients and
+    // the slab reductions (joined at the end of the call), in the forward pass the weight packing (joined in
+    // front of the first kernel that reads packed weights).  Timing runs stay on one stream.
     bool side = false;
-    if (backward && !u.prof) {
+    if (!u.prof) {
         if (u.use_side < 0) {
             u.use_side = getenv("MI_NO_SIDE_STREAM") ? 0 : 1;
             if (u.use_side) {
@@ -975,6 +977,23 @@ int run_list(mi_unet& u, std::vector<Step>& list, int backward, int bucket, char
     }
     bool pending = false;
     size_t nside = 0;
+    auto fork = [&]() -> int {      // the side stream waits for everything enqueued on the main stream so far
+        if (nside >= u.side_ev.size()) {
+            hipEvent_t e;
+            MI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            u.side_ev.push_back(e);
+        }
+        hipEvent_t ready = u.side_ev[nside++];
+        MI_HIP(hipEventRecord(ready, st));
+        MI_HIP(hipStreamWaitEvent(u.side, ready, 0));
+        return 0;
+    };
+    auto join = [&]() -> int {      // the main stream waits for everything enqueued on the side stream so far
+        MI_HIP(hipEventRecord(u.join_ev, u.side));
+        MI_HIP(hipStreamWaitEvent(st, u.join_ev, 0));
+        pending = false;
+        return 0;
+    };
     for (size_t i = 0; i < list.size(); ++i) {
         Step& s = list[i];
         if (bucket >= 0 && s.bucket != bucket) continue;
@@ -983,23 +1002,13 @@ int run_list(mi_unet& u, std::vector<Step>& list, int backward, int bucket, char
             MI_HIP(hipEventCreate(&ev.a)); MI_HIP(hipEventCreate(&ev.b));
             MI_HIP(hipEventRecord(ev.a, st));
         }
-        if (side && is_wgrad_kind(s.kind)) {
-            if (nside >= u.side_ev.size()) {
-                hipEvent_t e;
-                MI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-                u.side_ev.push_back(e);
-            }
-            hipEvent_t ready = u.side_ev[nside++];
-            MI_HIP(hipEventRecord(ready, st));
-            MI_HIP(hipStreamWaitEvent(u.side, ready, 0));
+        const bool on_side = side && (backward ? (is_wgrad_kind(s.kind) || s.kind == K_REDUCE) : s.kind == K_PACK);
+        if (on_side) {
+            if (int r = fork()) return r;
             if (int r = run_step(u, s, bases, training, seed, u.side)) return r;
             pending = true;
         } else {
-            if (pending && s.kind == K_REDUCE) {
-                MI_HIP(hipEventRecord(u.join_ev, u.side));
-                MI_HIP(hipStreamWaitEvent(st, u.join_ev, 0));
-                pending = false;
-            }
+            if (pending && !backward && s.kind == K_IGEMM) { if (int r = join()) return r; }
             if (int r = run_step(u, s, bases, training, seed, st)) return r;
         }
         if (u.prof) {
@@ -1008,10 +1017,7 @@ int run_list(mi_unet& u, std::vector<Step>& list, int backward, int bucket, char
             u.events.push_back(ev);
         }
     }
-    if (pending) {   // a list that does not end in a reduction: join anyway
-        MI_HIP(hipEventRecord(u.join_ev, u.side));
-        MI_HIP(hipStreamWaitEvent(st, u.join_ev, 0));
-    }
+    if (pending) { if (int r = join()) return r; }
     return 0;
 }
 
