@@ -7,6 +7,8 @@
 
 namespace {
 
+constexpr int C1_WGRAD_CG = 8;   // channels per thread of c1_s2_wgrad_kernel
+
 // ---- 1 -> N stride-2 convolution (k=3, pad=1), fine one-channel -> coarse N-channel ------
 // Thread = (coarse column, group of 8 output channels); a workgroup covers ppb = 256/(N/8) columns x ROWS rows.
 // The 72 weights of a kz plane sit in registers, the (2*ROWS+1) x 3 input values of the thread's column are
@@ -44,14 +46,6 @@ __global__ __launch_bounds__(256) void c1_s2_fwd_kernel(const C1Params p) {
     for (int kz = 0; kz < KZ; ++kz) {
         const int fz = (KZ == 3) ? 2 * cz - 1 + kz : 0;
         if ((unsigned)fz >= (unsigned)p.fd[0]) continue;   // uniform over the workgroup
-        float wr[9][8];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            const float4 a = *reinterpret_cast<const float4*>(wl + (kz * 9 + k) * N + grp * 8);
-            const float4 b = *reinterpret_cast<const float4*>(wl + (kz * 9 + k) * N + grp * 8 + 4);
-            wr[k][0] = a.x; wr[k][1] = a.y; wr[k][2] = a.z; wr[k][3] = a.w;
-            wr[k][4] = b.x; wr[k][5] = b.y; wr[k][6] = b.z; wr[k][7] = b.w;
-        }
         float xr[2 * ROWS + 1][3];
 #pragma unroll
         for (int j = 0; j < 2 * ROWS + 1; ++j) {
@@ -64,16 +58,22 @@ __global__ __launch_bounds__(256) void c1_s2_fwd_kernel(const C1Params p) {
                 xr[j][kx] = (rok && (unsigned)fx < (unsigned)p.fd[2]) ? row[fx] : 0.f;
             }
         }
+        // weights of one tap at a time from LDS (two 16-byte reads): keeps the register count low enough
+        // for six waves per SIMD, which is what hides the latency of the gather loads
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r)
+        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) {
+                const float4 a = *reinterpret_cast<const float4*>(wl + (kz * 9 + ky * 3 + kx) * N + grp * 8);
+                const float4 b = *reinterpret_cast<const float4*>(wl + (kz * 9 + ky * 3 + kx) * N + grp * 8 + 4);
+                const float w8[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
+                for (int r = 0; r < ROWS; ++r) {
                     const float xv = xr[2 * r + ky][kx];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[r][e] += xv * wr[ky * 3 + kx][e];
+                    for (int e = 0; e < 8; ++e) acc[r][e] += xv * w8[e];
                 }
+            }
     }
     float bv[8], s1[8], s2[8];
 #pragma unroll
@@ -226,18 +226,19 @@ __global__ __launch_bounds__(256) void c1_s2_T_kernel(const C1Params p) {
 template <class TR>
 __global__ __launch_bounds__(256) void c1_s2_wgrad_kernel(const C1Params p) {
     constexpr int ESZ = TR::ESZ;
+    constexpr int CG = C1_WGRAD_CG;   // channels per thread: few registers, many waves per SIMD
     extern __shared__ __attribute__((aligned(16))) float sm[];  // [4 waves][N][10]
     const int KZ = p.ndim == 3 ? 3 : 1;
     const int KK = KZ * 9;
     const int kz = blockIdx.y;
-    const int G = p.N / 8;
+    const int G = p.N / CG;
     for (int i = threadIdx.x; i < 4 * p.N * 10; i += 256) sm[i] = 0.f;
     __syncthreads();
     const size_t cpix = (size_t)p.cd[0] * p.cd[1] * p.cd[2];
     const size_t fpix = (size_t)p.fd[0] * p.fd[1] * p.fd[2];
-    float acc[8][9], accb[8];
+    float acc[CG][9], accb[CG];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < CG; ++e) {
         accb[e] = 0.f;
 #pragma unroll
         for (int k = 0; k < 9; ++k) acc[e][k] = 0.f;
@@ -248,20 +249,20 @@ __global__ __launch_bounds__(256) void c1_s2_wgrad_kernel(const C1Params p) {
     const int xb = blockIdx.x % xblocks, rb = blockIdx.x / xblocks, nrb = gridDim.x / xblocks;
     const int cx = xb * ppb + pl;
     const bool lane_ok = pl < ppb && cx < p.cd[2];
-    const bool second = grp * 8 >= p.n_y1;
+    const bool second = grp * CG >= p.n_y1;
     const char* ysrc = second ? p.y2 : p.y;
     const int ypitch = second ? p.y2_pitch : p.y_pitch;
-    const int ych = second ? p.y2_coff + grp * 8 - p.n_y1 : p.y_coff + grp * 8;
+    const int ych = second ? p.y2_coff + grp * CG - p.n_y1 : p.y_coff + grp * CG;
     const int nrows = p.nb * p.cd[0] * p.cd[1];
     if (rb < nrb)   // workgroups beyond the last full row block (grid not a multiple of xblocks) only write zeros
     for (int row = rb; row < nrows; row += nrb) {
         const int cy = row % p.cd[1]; const int r2 = row / p.cd[1];
         const int cz = r2 % p.cd[0]; const int img = r2 / p.cd[0];
         if (!lane_ok) continue;
-        float v[8];
-        load_n<TR, 8>(ysrc + (((size_t)row * p.cd[2] + cx) * ypitch + ych) * ESZ, v);
+        float v[CG];
+        load_n<TR, CG>(ysrc + (((size_t)row * p.cd[2] + cx) * ypitch + ych) * ESZ, v);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) accb[e] += v[e];
+        for (int e = 0; e < CG; ++e) accb[e] += v[e];
         const int fz = (p.ndim == 3) ? 2 * cz - 1 + kz : 0;
         if ((unsigned)fz >= (unsigned)p.fd[0]) continue;
         const float* xin = p.x1 + (size_t)img * fpix + (size_t)fz * p.fd[1] * p.fd[2];
@@ -279,14 +280,14 @@ __global__ __launch_bounds__(256) void c1_s2_wgrad_kernel(const C1Params p) {
 #pragma unroll
         for (int k = 0; k < 9; ++k)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e][k] += v[e] * xv[k];
+            for (int e = 0; e < CG; ++e) acc[e][k] += v[e] * xv[k];
     }
     (void)cpix;
     // lanes that share a channel group: xor-reduce over lane bits >= log2(G) when G divides the wave
     const bool pow2 = (64 % G) == 0;
     if (pow2) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < CG; ++e) {
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
                 float a = acc[e][k];
@@ -304,18 +305,18 @@ __global__ __launch_bounds__(256) void c1_s2_wgrad_kernel(const C1Params p) {
     if (pow2) {
         if ((threadIdx.x & 63) < G) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
+            for (int e = 0; e < CG; ++e) {
 #pragma unroll
-                for (int k = 0; k < 9; ++k) mine[(grp * 8 + e) * 10 + k] = acc[e][k];
-                mine[(grp * 8 + e) * 10 + 9] = accb[e];
+                for (int k = 0; k < 9; ++k) mine[(grp * CG + e) * 10 + k] = acc[e][k];
+                mine[(grp * CG + e) * 10 + 9] = accb[e];
             }
         }
     } else if (pl < ppb) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < CG; ++e) {
 #pragma unroll
-            for (int k = 0; k < 9; ++k) atomicAdd(&mine[(grp * 8 + e) * 10 + k], acc[e][k]);
-            atomicAdd(&mine[(grp * 8 + e) * 10 + 9], accb[e]);
+            for (int k = 0; k < 9; ++k) atomicAdd(&mine[(grp * CG + e) * 10 + k], acc[e][k]);
+            atomicAdd(&mine[(grp * CG + e) * 10 + 9], accb[e]);
         }
     }
     __syncthreads();
@@ -536,7 +537,7 @@ int launch_c1_s2_T(int dtype, const C1Params& p, hipStream_t st) {
 
 // slabs (= workgroups along x) of the weight-gradient kernel: whole column blocks times row blocks
 int c1_wgrad_slabs(int N, const int cd[3]) {
-    const int ppb = 256 / (N / 8);
+    const int ppb = 256 / (N / C1_WGRAD_CG);
     const int xblocks = (cd[2] + ppb - 1) / ppb;
     int rb = 1024 / xblocks;
     if (rb < 1) rb = 1;
@@ -545,7 +546,7 @@ int c1_wgrad_slabs(int N, const int cd[3]) {
 
 // partial: [nsplit][KK][N] floats, partial_bias: [nsplit][N] floats
 int launch_c1_s2_wgrad(int dtype, const C1Params& p, hipStream_t st) {
-    MI_CHECK(p.N % 8 == 0 && p.N >= 8 && p.N <= 512, "N must be a multiple of 8, at most 512");
+    MI_CHECK(p.N % 8 == 0 && p.N >= 8 && p.N <= 512 && p.N / C1_WGRAD_CG <= 256, "N must be a multiple of 8, at most 512");
     MI_CHECK(p.n_y1 % 8 == 0 && p.n_y1 > 0 && (p.n_y1 >= p.N || p.y2 != nullptr), "second source missing or misaligned");
     MI_CHECK(p.nsplit == c1_wgrad_slabs(p.N, p.cd), "nsplit must come from c1_wgrad_slabs()");
     const size_t lds = (size_t)4 * p.N * 10 * sizeof(float);
