@@ -120,16 +120,18 @@ __global__ __launch_bounds__(256) void c1_s2_fwd_kernel(const C1Params p) {
 }
 
 // ---- N -> 1 stride-2 transposed convolution (k=3, pad=1, output_padding=1) ---------------
-// Phase 1: every coarse pixel of the tile (plus a one-pixel halo on the high side) forms its KK tap
-// products d[k] = <Y[c][:], w[:][k]> once and parks them in LDS.  Phase 2: every fine pixel sums the
-// 1, 2, 4 (or 8) products that land on it: per dimension an even fine index takes tap 1 of its own
-// coarse pixel, an odd one takes tap 2 of its own and tap 0 of the next coarse pixel.
+// Phase 1: every thread forms the KK tap products d[k] = <Y[c][:], w[:][k]> of one coarse pixel of the
+// workgroup's patch and parks them in LDS.  Phase 2: every fine pixel sums the 1, 2, 4 (or 8) products that
+// land on it: per dimension an even fine index takes tap 1 of its own coarse pixel, an odd one takes tap 2
+// of its own and tap 0 of the next coarse pixel.  The patch is exactly one pixel per thread; a workgroup
+// writes the fine pixels of all patch pixels but the last row / column / plane (whose "next" neighbour lies
+// in the next patch), so consecutive patches overlap by one pixel and no second pass is needed.
 template <class TR, int KZ>
 __global__ __launch_bounds__(256) void c1_s2_T_kernel(const C1Params p) {
     constexpr int ESZ = TR::ESZ;
     constexpr int KK = KZ * 9;
-    constexpr int TZ = KZ == 3 ? 4 : 1, TY = 8, TX = KZ == 3 ? 8 : 32;
-    constexpr int PZ = KZ == 3 ? TZ + 1 : 1, PY = TY + 1, PX = TX + 1, NP = PZ * PY * PX;
+    constexpr int PZ = KZ == 3 ? 4 : 1, PY = 8, PX = KZ == 3 ? 8 : 32, NP = PZ * PY * PX;   // NP = 256
+    constexpr int OZ = KZ == 3 ? PZ - 1 : 1, OY = PY - 1, OX = PX - 1;                       // pixels a workgroup owns
     extern __shared__ __attribute__((aligned(16))) float sm[];  // weights [KK][N], then products [KK][NP]
     __shared__ float red[2][4];
     const int N = p.N;
@@ -140,19 +142,19 @@ __global__ __launch_bounds__(256) void c1_s2_T_kernel(const C1Params p) {
         wl[k * N + n] = p.w[i];
     }
     __syncthreads();
-    const int tzn = (p.cd[0] + TZ - 1) / TZ;
+    const int tzn = (p.cd[0] + OZ - 1) / OZ;
     const int img = blockIdx.z / tzn;
-    const int cz0 = (blockIdx.z % tzn) * TZ, cy0 = blockIdx.y * TY, cx0 = blockIdx.x * TX;
+    const int cz0 = (blockIdx.z % tzn) * OZ, cy0 = blockIdx.y * OY, cx0 = blockIdx.x * OX;
     const size_t cpix = (size_t)p.cd[0] * p.cd[1] * p.cd[2];
     const size_t fpix = (size_t)p.fd[0] * p.fd[1] * p.fd[2];
-    for (int i = threadIdx.x; i < NP; i += 256) {
-        const int px = i % PX; const int r = i / PX;
-        const int py = r % PY, pz = r / PY;
-        const int cz = cz0 + pz, cy = cy0 + py, cx = cx0 + px;
+    const int tx = threadIdx.x % PX, ty = (threadIdx.x / PX) % PY, tz = threadIdx.x / (PX * PY);
+    const int cz = cz0 + tz, cy = cy0 + ty, cx = cx0 + tx;
+    const bool inside = cz < p.cd[0] && cy < p.cd[1] && cx < p.cd[2];
+    {
         float d[KK];
 #pragma unroll
         for (int k = 0; k < KK; ++k) d[k] = 0.f;
-        if (cz < p.cd[0] && cy < p.cd[1] && cx < p.cd[2]) {
+        if (inside) {
             const size_t gp = (size_t)img * cpix + ((size_t)cz * p.cd[1] + cy) * p.cd[2] + cx;
             const char* src = p.y + (gp * p.y_pitch + p.y_coff) * ESZ;
             const char* src2 = p.y2 ? p.y2 + (gp * p.y2_pitch + p.y2_coff) * ESZ : nullptr;
@@ -168,15 +170,13 @@ __global__ __launch_bounds__(256) void c1_s2_T_kernel(const C1Params p) {
             }
         }
 #pragma unroll
-        for (int k = 0; k < KK; ++k) D[k * NP + i] = d[k];
+        for (int k = 0; k < KK; ++k) D[k * NP + threadIdx.x] = d[k];
     }
     __syncthreads();
-    const int tx = threadIdx.x % TX, ty = (threadIdx.x / TX) % TY, tz = threadIdx.x / (TX * TY);
-    const int cz = cz0 + tz, cy = cy0 + ty, cx = cx0 + tx;
-    const bool valid = cz < p.cd[0] && cy < p.cd[1] && cx < p.cd[2];
+    const bool owner = inside && tx < OX && ty < OY && (KZ == 1 || tz < OZ);
     const float bias = p.bias ? p.bias[0] : 0.f;
     float s1 = 0.f, s2 = 0.f;
-    if (valid) {
+    if (owner) {
         float* out = p.x1_out + (size_t)img * fpix;
 #pragma unroll
         for (int pz = 0; pz < (KZ == 3 ? 2 : 1); ++pz)
@@ -506,11 +506,11 @@ int run_c1_fwd(const C1Params& p, hipStream_t st) {
 template <class TR, int KZ>
 int run_c1_T(const C1Params& p, hipStream_t st) {
     constexpr int KK = KZ * 9;
-    constexpr int TZ = KZ == 3 ? 4 : 1, TY = 8, TX = KZ == 3 ? 8 : 32;
-    constexpr int NP = (KZ == 3 ? TZ + 1 : 1) * (TY + 1) * (TX + 1);
-    const size_t lds = (size_t)(KK * p.N + KK * NP) * sizeof(float);
+    constexpr int PZ = KZ == 3 ? 4 : 1, PY = 8, PX = KZ == 3 ? 8 : 32;
+    constexpr int OZ = KZ == 3 ? PZ - 1 : 1, OY = PY - 1, OX = PX - 1;
+    const size_t lds = (size_t)(KK * p.N + KK * 256) * sizeof(float);
     if (int rc = small_lds(c1_s2_T_kernel<TR, KZ>, lds)) return rc;
-    dim3 grid((p.cd[2] + TX - 1) / TX, (p.cd[1] + TY - 1) / TY, p.nb * ((p.cd[0] + TZ - 1) / TZ));
+    dim3 grid((p.cd[2] + OX - 1) / OX, (p.cd[1] + OY - 1) / OY, p.nb * ((p.cd[0] + OZ - 1) / OZ));
     hipLaunchKernelGGL((c1_s2_T_kernel<TR, KZ>), grid, dim3(256), lds, st, p);
     return check_launch("c1_s2_T");
 }
