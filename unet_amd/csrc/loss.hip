@@ -29,9 +29,11 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const LossParams p) {
         const float zi = z[i];
         const float t = load_label(p.target, p.tdtype, (size_t)b * p.npix + i, p.fold2);
         const float e = __expf(-fabsf(zi));
-        const float s = zi >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+        const float inv = __frcp_rn(1.f + e);
+        const float s = zi >= 0.f ? inv : e * inv;
         a0 += s * t; a1 += s; a2 += t;
-        a3 += fmaxf(zi, 0.f) - zi * t + log1pf(e);
+        // log(1 + e) for e in (0, 1]: the series below 2^-12 keeps the relative accuracy log1p would give
+        a3 += fmaxf(zi, 0.f) - zi * t + (e < 2.44140625e-4f ? e * (1.f - 0.5f * e) : __logf(1.f + e));
     }
     a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
     const int w = threadIdx.x >> 6;
