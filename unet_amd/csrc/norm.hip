@@ -395,7 +395,8 @@ int launch_norm_fwd(int dtype, const NormParams& p, hipStream_t st) {
     const int vec = dtype ? 8 : 4;
     MI_CHECK(p.c % vec == 0, "channels must be a multiple of the 16-byte vector");
     MI_CHECK(p.c / vec <= 256, "too many channels for the norm kernels");
-    const int gx = norm_blocks(p.npix, p.c, vec, 8, 65535);
+    int gx = norm_blocks(p.npix, p.c, vec, 8, 65535);
+    if ((long long)gx * p.nb < 1024) gx = norm_blocks(p.npix, p.c, vec, 4, 65535);   // small tensors: shorter workgroups, more of them
     const size_t lds = (size_t)p.c * 2 * sizeof(float);
     if (dtype) hipLaunchKernelGGL(norm_fwd_kernel<BF16>, dim3(gx, p.nb), dim3(256), lds, st, p);
     else hipLaunchKernelGGL(norm_fwd_kernel<F32>, dim3(gx, p.nb), dim3(256), lds, st, p);
@@ -422,7 +423,8 @@ int launch_norm_bwd(int dtype, const NormParams& p, hipStream_t st) {
     if (dtype) hipLaunchKernelGGL(norm_bwd_reduce_kernel<BF16>, dim3(gr, p.nb), dim3(256), lds_r, st, p);
     else hipLaunchKernelGGL(norm_bwd_reduce_kernel<F32>, dim3(gr, p.nb), dim3(256), lds_r, st, p);
     if (int r = check_launch("norm_bwd_reduce")) return r;
-    const int gx = norm_blocks(p.npix, p.c, vec, 8, 65535);
+    int gx = norm_blocks(p.npix, p.c, vec, 8, 65535);
+    if ((long long)gx * p.nb < 1024) gx = norm_blocks(p.npix, p.c, vec, 4, 65535);
     if (dtype) hipLaunchKernelGGL(norm_bwd_apply_kernel<BF16>, dim3(gx, p.nb), dim3(256), lds, st, p);
     else hipLaunchKernelGGL(norm_bwd_apply_kernel<F32>, dim3(gx, p.nb), dim3(256), lds, st, p);
     return check_launch("norm_bwd_apply");
