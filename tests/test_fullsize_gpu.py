@@ -1,0 +1,111 @@
+"""Properties that hold at any size, checked at the benchmark's full size (32 slices of 512 x 512, channels
+16-256), where the CPU oracle would take minutes:
+
+* instance norm is per sample, so permuting the batch permutes the logits bit for bit and leaves every
+  parameter gradient unchanged up to summation order;
+* the loss of a batch is the mean of the losses of its halves (Dice and BCE are means over samples / pixels);
+* a sliding window as large as the image is the plain forward pass;
+* the directional derivative of the loss along a random direction matches <gradient, direction> (fp32);
+* one fused trainer step equals forward + loss + backward + AdamW done through autograd.
+"""
+import pytest
+import torch
+
+import unet_amd
+from test_unet_gpu import disks
+
+pytestmark = pytest.mark.gpu
+CH = (16, 32, 64, 128, 256)
+
+
+def _model(dtype, dev, seed=0):
+    torch.manual_seed(seed)
+    return unet_amd.UNet(2, 1, 1, CH, (2, 2, 2, 2), num_res_units=2, compute_dtype=dtype).to(dev)
+
+
+def _batch(nb, size, dev, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(nb, 1, size, size, generator=g)
+    t = disks(nb, (size, size), seed + 1, with_two=True)
+    return x.to(dev), t.to(dev)
+
+
+def test_batch_permutation_equivariance_full_size(dev):
+    m = _model(torch.bfloat16, dev).train()
+    x, t = _batch(32, 512, dev)
+    perm = torch.randperm(32, generator=torch.Generator().manual_seed(1)).to(dev)
+    loss = unet_amd.DiceCELoss(sigmoid=True, fold_label_two=True)
+    y = m(x)
+    l = loss(y, t); l.backward()
+    g = [p.grad.clone() for p in m.parameters()]
+    m.zero_grad()
+    yp = m(x[perm])
+    lp = loss(yp, t[perm]); lp.backward()
+    torch.cuda.synchronize()
+    assert torch.equal(yp, y[perm])                                   # same samples, same bits
+    assert abs(float(l.detach()) - float(lp.detach())) < 1e-6
+    gn = torch.sqrt(sum((a.float() ** 2).sum() for a in g))
+    dn = torch.sqrt(sum(((a - p.grad).float() ** 2).sum() for a, p in zip(g, m.parameters())))
+    assert float(dn / gn) < 1e-3                                      # only the summation order over the batch changes
+
+
+def test_loss_of_batch_is_mean_of_halves_full_size(dev):
+    m = _model(torch.bfloat16, dev).eval()
+    x, t = _batch(32, 512, dev)
+    loss = unet_amd.DiceCELoss(sigmoid=True, fold_label_two=True)
+    with torch.no_grad():
+        y = m(x)
+        whole = float(loss(y, t))
+        halves = 0.5 * (float(loss(y[:16], t[:16])) + float(loss(y[16:], t[16:])))
+    assert abs(whole - halves) < 1e-6
+
+
+def test_window_as_large_as_the_image_is_the_forward_pass(dev):
+    m = _model(torch.bfloat16, dev).eval()
+    x, _ = _batch(4, 512, dev)
+    with torch.no_grad():
+        a = m(x)
+        b = unet_amd.sliding_window_inference(x, (512, 512), 4, m)
+    assert torch.equal(a, b)
+
+
+def test_directional_derivative_matches_gradient_fp32(dev):
+    m = _model(torch.float32, dev).eval()            # eval: no dropout; norm statistics are per sample anyway
+    x, t = _batch(2, 256, dev)
+    loss = unet_amd.DiceCELoss(sigmoid=True, fold_label_two=True)
+    l0 = loss(m(x), t); l0.backward()
+    # parameters are views of the flat buffer, in a different order than parameters(): build the direction per tensor
+    gen = torch.Generator().manual_seed(9)
+    dirs = [torch.randn(p.shape, generator=gen).to(dev) * p.detach().abs().mean().clamp(min=1e-3) for p in m.parameters()]
+    gd = sum(float((p.grad.double() * d.double()).sum()) for p, d in zip(m.parameters(), dirs))
+    eps = 1e-2
+    with torch.no_grad():
+        for p, d in zip(m.parameters(), dirs):
+            p.add_(eps * d)
+        lp = float(loss(m(x), t))
+        for p, d in zip(m.parameters(), dirs):
+            p.sub_(2 * eps * d)
+        lm = float(loss(m(x), t))
+    fd = (lp - lm) / (2 * eps)
+    assert abs(fd - gd) < 2e-2 * max(abs(gd), 1e-3), (fd, gd)
+
+
+def test_fused_step_equals_autograd_step_fp32(dev):
+    x, t = _batch(4, 128, dev)
+    ma, mb = _model(torch.float32, dev, seed=4).train(), _model(torch.float32, dev, seed=4).train()
+    loss = unet_amd.DiceCELoss(sigmoid=True, fold_label_two=True)
+    oa = unet_amd.AdamW(ma.parameters(), lr=1e-3, weight_decay=1e-5, model=ma)
+    ob = unet_amd.AdamW(mb.parameters(), lr=1e-3, weight_decay=1e-5, model=mb)
+    tr = unet_amd.Trainer(ma, loss, oa)
+    tr.step(x, t)
+    ob.zero_grad(); loss(mb(x), t).backward()
+    torch.cuda.synchronize()
+    # same kernels, same order: the gradient the trainer fed to AdamW equals the autograd gradient
+    ga = tr._grad
+    for (name, shape, n, o, _), p in zip(mb._ptable_ordered, mb.parameters()):
+        d = float((ga[o:o + n] - p.grad.flatten()).abs().max())
+        assert d <= 1e-6 * max(float(p.grad.abs().max()), 1e-6), name
+    ob.step()
+    torch.cuda.synchronize()
+    # AdamW turns rounding-level gradients into +-lr steps: one step of lr = 1e-3
+    assert float((ma.flat_parameters() - mb.flat_parameters()).abs().max()) < 2.5e-3
