@@ -8,6 +8,7 @@
 namespace {
 
 constexpr int C1_WGRAD_CG = 8;   // channels per thread of c1_s2_wgrad_kernel
+constexpr int C1T_YP = 4;        // patches along y per workgroup of c1_s2_T_kernel
 
 // ---- 1 -> N stride-2 convolution (k=3, pad=1), fine one-channel -> coarse N-channel ------
 // Thread = (coarse column, group of 8 output channels); a workgroup covers ppb = 256/(N/8) columns x ROWS rows.
@@ -142,15 +143,70 @@ __global__ __launch_bounds__(256) void c1_s2_T_kernel(const C1Params p) {
         wl[k * N + n] = p.w[i];
     }
     __syncthreads();
+    constexpr int TB = (KK + 15) / 16;
+    const int NC = (N + 31) & ~31;
+    unsigned short* wb = reinterpret_cast<unsigned short*>(D + KK * NP);   // bf16: [TB * 16 tap rows][NC], NC = N rounded up to 32
+    if constexpr (TR::ESZ == 2) {
+        for (int i = threadIdx.x; i < TB * 16 * NC; i += 256) {
+            const int n = i % NC, kk = i / NC;
+            wb[i] = (kk < KK && n < N) ? f32_to_bf16(wl[kk * N + n]) : (unsigned short)0;
+        }
+        __syncthreads();
+    }
     const int tzn = (p.cd[0] + OZ - 1) / OZ;
     const int img = blockIdx.z / tzn;
-    const int cz0 = (blockIdx.z % tzn) * OZ, cy0 = blockIdx.y * OY, cx0 = blockIdx.x * OX;
+    const int cz0 = (blockIdx.z % tzn) * OZ, cx0 = blockIdx.x * OX;
     const size_t cpix = (size_t)p.cd[0] * p.cd[1] * p.cd[2];
     const size_t fpix = (size_t)p.fd[0] * p.fd[1] * p.fd[2];
     const int tx = threadIdx.x % PX, ty = (threadIdx.x / PX) % PY, tz = threadIdx.x / (PX * PY);
+    const float bias = p.bias ? p.bias[0] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    // a workgroup walks C1T_YP consecutive patches along y with the weight images prepared once
+    for (int yi = 0; yi < C1T_YP; ++yi) {
+    const int cy0 = (blockIdx.y * C1T_YP + yi) * OY;
+    if (cy0 >= p.cd[1]) break;
+    if (yi) __syncthreads();                      // the previous patch's products have been consumed
     const int cz = cz0 + tz, cy = cy0 + ty, cx = cx0 + tx;
     const bool inside = cz < p.cd[0] && cy < p.cd[1] && cx < p.cd[2];
-    {
+    if constexpr (TR::ESZ == 2) {
+        // bf16: the tap products are one small GEMM per 16 pixels, D[tap][pixel] = W[tap][channel] * Y[channel][pixel],
+        // on the matrix cores: A = weights (16 tap rows x 32 channels from LDS, bf16, rows >= KK zero), B = the
+        // pixel's channels straight from memory (lane (pixel, g) holds channels 8g..8g+7 of a 32-channel chunk)
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) {
+            const int pl = wave * 64 + mf * 16 + lr;                // pixel of the patch this lane feeds
+            const int qx = pl % PX, qy = (pl / PX) % PY, qz = pl / (PX * PY);
+            const int pz = cz0 + qz, py = cy0 + qy, px = cx0 + qx;
+            const bool ok = pz < p.cd[0] && py < p.cd[1] && px < p.cd[2];
+            const size_t gp = (size_t)img * cpix + ((size_t)pz * p.cd[1] + py) * p.cd[2] + px;
+            v4f acc[TB];
+#pragma unroll
+            for (int tb = 0; tb < TB; ++tb) acc[tb] = v4f{0.f, 0.f, 0.f, 0.f};
+            for (int n0 = 0; n0 < N; n0 += 32) {
+                const int ch = n0 + 8 * g;
+                uint4 b = make_uint4(0u, 0u, 0u, 0u);
+                if (ok && ch < N) {
+                    const char* src = (p.y2 && ch >= p.n_y1) ? p.y2 + (gp * p.y2_pitch + p.y2_coff + ch - p.n_y1) * ESZ
+                                                              : p.y + (gp * p.y_pitch + p.y_coff + ch) * ESZ;
+                    b = *reinterpret_cast<const uint4*>(src);
+                }
+#pragma unroll
+                for (int tb = 0; tb < TB; ++tb) {
+                    const uint4 a = *reinterpret_cast<const uint4*>(wb + (size_t)(tb * 16 + lr) * NC + ch);
+                    acc[tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b), acc[tb], 0, 0, 0);
+                }
+            }
+            // lane (pixel lr, g) holds taps 4g..4g+3 of each 16-tap block
+#pragma unroll
+            for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = tb * 16 + 4 * g + j;
+                    if (k < KK) D[k * NP + pl] = acc[tb][j];
+                }
+        }
+    } else {
         float d[KK];
 #pragma unroll
         for (int k = 0; k < KK; ++k) d[k] = 0.f;
@@ -174,8 +230,6 @@ __global__ __launch_bounds__(256) void c1_s2_T_kernel(const C1Params p) {
     }
     __syncthreads();
     const bool owner = inside && tx < OX && ty < OY && (KZ == 1 || tz < OZ);
-    const float bias = p.bias ? p.bias[0] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
     if (owner) {
         float* out = p.x1_out + (size_t)img * fpix;
 #pragma unroll
@@ -206,6 +260,7 @@ __global__ __launch_bounds__(256) void c1_s2_T_kernel(const C1Params p) {
                 *reinterpret_cast<float2*>(out + fo) = make_float2(o[0] + bias, o[1] + bias);
             }
     }
+    }   // patches
     if (p.stats) {
         s1 = wave_sum(s1); s2 = wave_sum(s2);
         const int w = threadIdx.x >> 6;
@@ -508,9 +563,11 @@ int run_c1_T(const C1Params& p, hipStream_t st) {
     constexpr int KK = KZ * 9;
     constexpr int PZ = KZ == 3 ? 4 : 1, PY = 8, PX = KZ == 3 ? 8 : 32;
     constexpr int OZ = KZ == 3 ? PZ - 1 : 1, OY = PY - 1, OX = PX - 1;
-    const size_t lds = (size_t)(KK * p.N + KK * 256) * sizeof(float);
+    // weights fp32 [KK][N], tap products [KK][256], and (bf16) the weight image for the matrix cores
+    const size_t lds = (size_t)(KK * p.N + KK * 256) * sizeof(float) + (TR::ESZ == 2 ? (size_t)((KK + 15) / 16) * 16 * ((p.N + 31) & ~31) * 2 : 0);
     if (int rc = small_lds(c1_s2_T_kernel<TR, KZ>, lds)) return rc;
-    dim3 grid((p.cd[2] + OX - 1) / OX, (p.cd[1] + OY - 1) / OY, p.nb * ((p.cd[0] + OZ - 1) / OZ));
+    const int nyp = (p.cd[1] + OY - 1) / OY;
+    dim3 grid((p.cd[2] + OX - 1) / OX, (nyp + C1T_YP - 1) / C1T_YP, p.nb * ((p.cd[0] + OZ - 1) / OZ));
     hipLaunchKernelGGL((c1_s2_T_kernel<TR, KZ>), grid, dim3(256), lds, st, p);
     return check_launch("c1_s2_T");
 }
