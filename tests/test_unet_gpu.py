@@ -63,7 +63,7 @@ CONFIGS = [
     (2, (16, 32, 64), 2, 2, (32, 48)),
     (2, (16, 32, 64), 1, 1, (16, 16)),
     (2, (16, 32, 64, 128, 256), 2, 2, (64, 64)),
-    (2, (32, 64, 128, 256, 512), 2, 1, (32, 32)),
+    (2, (32, 64, 128, 256, 512), 2, 1, (64, 64)),   # 4 x 4 pixels at the bottom: a 2 x 2 instance norm amplifies fp32 rounding past 1e-4
     (3, (16, 32), 2, 1, (16, 16, 16)),
     (3, (16, 32, 64, 128, 256), 2, 1, (32, 32, 32)),
     (2, (32, 32), 2, 1, (16, 16)),

@@ -8,6 +8,7 @@
 namespace {
 
 constexpr int C1_WGRAD_CG = 8;   // channels per thread of c1_s2_wgrad_kernel
+constexpr int C1F_YG = 1;        // groups of four coarse rows per workgroup of c1_s2_fwd_kernel
 constexpr int C1T_YP = 4;        // patches along y per workgroup of c1_s2_T_kernel
 
 // ---- 1 -> N stride-2 convolution (k=3, pad=1), fine one-channel -> coarse N-channel ------
@@ -32,12 +33,22 @@ __global__ __launch_bounds__(256) void c1_s2_fwd_kernel(const C1Params p) {
     __syncthreads();
     const int grp = threadIdx.x % G, pl = threadIdx.x / G;
     const int cz = blockIdx.z % p.cd[0], img = blockIdx.z / p.cd[0];
-    const int cy0 = blockIdx.y * ROWS;
     const int cx = blockIdx.x * ppb + pl;
     const bool lane_ok = pl < ppb && cx < p.cd[2];
     const size_t fpix = (size_t)p.fd[0] * p.fd[1] * p.fd[2];
     const size_t cpix = (size_t)p.cd[0] * p.cd[1] * p.cd[2];
     const float* xin = p.x1 + (size_t)img * fpix;
+    float bv[8], s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ch = grp * 8 + e;
+        bv[e] = (p.bias && ch >= p.bias_c0 && pl < ppb) ? p.bias[ch - p.bias_c0] : 0.f;
+        s1[e] = 0.f; s2[e] = 0.f;
+    }
+    // a workgroup walks C1F_YG consecutive groups of ROWS coarse rows with the weight image staged once
+    for (int yg = 0; yg < C1F_YG; ++yg) {
+    const int cy0 = (blockIdx.y * C1F_YG + yg) * ROWS;
+    if (cy0 >= p.cd[1]) break;
     float acc[ROWS][8];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r)
@@ -76,13 +87,6 @@ __global__ __launch_bounds__(256) void c1_s2_fwd_kernel(const C1Params p) {
                 }
             }
     }
-    float bv[8], s1[8], s2[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int ch = grp * 8 + e;
-        bv[e] = (p.bias && ch >= p.bias_c0 && pl < ppb) ? p.bias[ch - p.bias_c0] : 0.f;
-        s1[e] = 0.f; s2[e] = 0.f;
-    }
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         const int cy = cy0 + r;
@@ -100,6 +104,7 @@ __global__ __launch_bounds__(256) void c1_s2_fwd_kernel(const C1Params p) {
             store_n<TR, 8>(dst, o);
         }
     }
+    }   // row groups
     if (p.stats) {
         // fixed-order reduction over the workgroup's columns, then fp64 accumulators
         if (pl < ppb) {
@@ -553,7 +558,7 @@ int run_c1_fwd(const C1Params& p, hipStream_t st) {
     const int ppb = 256 / (p.N / 8);
     const size_t lds = (size_t)(p.N * KK + 2 * ppb * p.N) * sizeof(float);
     if (int rc = small_lds(c1_s2_fwd_kernel<TR, KZ>, lds)) return rc;
-    dim3 grid((p.cd[2] + ppb - 1) / ppb, (p.cd[1] + ROWS - 1) / ROWS, p.nb * p.cd[0]);
+    dim3 grid((p.cd[2] + ppb - 1) / ppb, (p.cd[1] + ROWS * C1F_YG - 1) / (ROWS * C1F_YG), p.nb * p.cd[0]);
     hipLaunchKernelGGL((c1_s2_fwd_kernel<TR, KZ>), grid, dim3(256), lds, st, p);
     return check_launch("c1_s2_fwd");
 }
