@@ -969,11 +969,7 @@ int run_list(mi_unet& u, std::vector<Step>& list, int backward, int bucket, char
         if (u.use_side < 0) {
             u.use_side = getenv("MI_NO_SIDE_STREAM") ? 0 : 1;
             if (u.use_side) {
-                // lowest priority: the side work fills what the critical chain on the caller's stream leaves idle
-                int least = 0, greatest = 0;
-                if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = 0; }
-                if (getenv("MI_SIDE_NO_PRIO")) least = 0;
-                if (hipStreamCreateWithPriority(&u.side, hipStreamNonBlocking, least) != hipSuccess) { (void)hipGetLastError(); u.use_side = 0; }
+                if (hipStreamCreateWithFlags(&u.side, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); u.use_side = 0; }
                 else if (hipEventCreateWithFlags(&u.join_ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); u.use_side = 0; }
             }
         }
