@@ -36,7 +36,7 @@ namespace {
 
 enum StepKind {
     K_IGEMM, K_WGRAD, K_NORM_FWD, K_NORM_BWD, K_C1_FWD, K_C1_T, K_C1_WGRAD, K_STENCIL, K_STENCIL_WGRAD, K_ADD,
-    K_MEMSET, K_REDUCE, K_PACK
+    K_MEMSET, K_REDUCE, K_PACK, K_KFINISH
 };
 enum Base { B_ARENA, B_PARAMS, B_GRADS, B_XIN, B_LOGITS, B_DLOGITS, B_NBASE };
 
@@ -231,6 +231,31 @@ struct Builder {
             s.bytes = (ipix * K + opix * N * (addend ? 2.0 : 1.0)) * u.esz + (double)(*ntaps_out) * K * N * u.esz;
         }
         if (&list == &u.fwd) u.flops_fwd += s.work; else u.flops_bwd += s.work;
+        // Too few workgroups for the chip and several contraction chunks (deep levels of small batches, 3-D
+        // patches): split the chunks over more workgroups and finish the layer in a second, tiny launch.
+        {
+            long long wgs = 0; int nkc = 1;
+            igemm_parallelism(u.dt, p, &wgs, &nkc);
+            int ks = 1;
+            if (!getenv("MI_NO_KSPLIT") && wgs < 256 && nkc >= 2 && N % 4 == 0 && N / 4 <= 256) {
+                ks = (int)((512 + wgs - 1) / wgs);
+                if (ks > nkc) ks = nkc;
+                if (ks > 8) ks = 8;
+            }
+            if (ks > 1) {
+                const size_t npo = (size_t)u.nb * p.od[0] * p.od[1] * p.od[2];
+                const size_t kp = alloc((size_t)ks * npo * N * sizeof(float));
+                p.ksplit = ks;
+                REL(s, p, kpart, B_ARENA, kp);
+                const std::string lname = s.layer;
+                const Step main_step = s;              // copy: push() may move the vector's storage
+                Step& f = push(list, K_KFINISH, lname + " (finish)");
+                f.ig = main_step.ig; f.rel = main_step.rel; f.dtype = main_step.dtype;
+                f.kernel = u.dt ? "ksplit_finish_kernel<BF16>" : "ksplit_finish_kernel<F32>";
+                f.work = 0; f.work_is_flops = 0;
+                f.bytes = (double)npo * N * (ks * 4.0 + u.esz);
+            }
+        }
         return true;
     }
 
@@ -920,6 +945,7 @@ int run_step(mi_unet& u, Step& s, char* const* bases, int training, uint64_t see
     if (!bases_ok(s, bases)) { mi_set_error("step '" + s.layer + "' needs a buffer the caller did not pass"); return -1; }
     switch (s.kind) {
         case K_IGEMM: return launch_igemm(s.dtype, resolve(s, s.ig, bases), st);
+        case K_KFINISH: return launch_ksplit_finish(s.dtype, resolve(s, s.ig, bases), st);
         case K_WGRAD: return launch_wgrad(s.dtype, resolve(s, s.wg, bases), st);
         case K_NORM_FWD:
         case K_NORM_BWD: {

@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     const int img = bid / p.ntile[0];
     const int slot = blockIdx.x % MI_NSLOT;
     const int n0 = blockIdx.y * NT;
-    const int ph = blockIdx.z;
+    const int ph = blockIdx.z % p.nphase;
+    const int ksp = blockIdx.z / p.nphase;       // contraction split: which share of the chunks this workgroup takes
     const int bz0 = tzi << p.tlog[0], by0 = tyi << p.tlog[1], bx0 = txi << p.tlog[2];
     const int PP = p.pd[0] * p.pd[1] * p.pd[2];
     char* smA = smem;
@@ -84,7 +85,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
         for (int nf = 0; nf < NFRAG; ++nf) acc[mf][nf] = v4f{0.f, 0.f, 0.f, 0.f};
 
-    for (int kc = 0; kc < p.K; kc += KCE) {
+    int kc_begin = 0, kc_end = p.K;
+    if (p.ksplit > 1) {
+        const int nkc = (p.K + KCE - 1) / KCE, per = (nkc + p.ksplit - 1) / p.ksplit;
+        kc_begin = ksp * per * KCE;
+        kc_end = min(p.K, kc_begin + per * KCE);
+    }
+    for (int kc = kc_begin; kc < kc_end; kc += KCE) {
         const char* src;
         int spitch, scoff;
         if (kc < p.in0_c) { src = p.in0; spitch = p.in0_pitch; scoff = p.in0_coff + kc; }
@@ -178,7 +185,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     }
 
     // ---- epilogue: statistics, bias, addend, store -----------------------------
-    const bool do_stats = p.stats != nullptr;
+    const bool do_stats = p.stats != nullptr && p.ksplit <= 1;
     float s1[NFRAG][4], s2[NFRAG][4];
 #pragma unroll
     for (int nf = 0; nf < NFRAG; ++nf)
@@ -200,7 +207,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
                     s1[nf][j] += v; s2[nf][j] += v * v;
                 }
         }
-        if (valid) {
+        if (valid && p.ksplit > 1) {
+            // contraction split: raw fp32 partial sums [split][output pixel][N]; the finishing kernel adds them up
+            const int oz = bz * p.so + p.phase_off[ph][0], oy = by * p.so + p.phase_off[ph][1],
+                      ox = bx * p.so + p.phase_off[ph][2];
+            const size_t op = ((size_t)(img * p.od[0] + oz) * p.od[1] + oy) * p.od[2] + ox;
+            const size_t npo = (size_t)p.nb * p.od[0] * p.od[1] * p.od[2];
+            float* dst = p.kpart + ((size_t)ksp * npo + op) * p.N + n0;
+#pragma unroll
+            for (int nf = 0; nf < NFRAG; ++nf) {
+                const int tc = chan_of_row<NFRAG>(nf, 4 * g);     // four consecutive channels
+                *reinterpret_cast<float4*>(dst + tc) = make_float4(acc[mf][nf][0], acc[mf][nf][1], acc[mf][nf][2], acc[mf][nf][3]);
+            }
+        } else if (valid) {
             const int oz = bz * p.so + p.phase_off[ph][0], oy = by * p.so + p.phase_off[ph][1],
                       ox = bx * p.so + p.phase_off[ph][2];
             const size_t op = ((size_t)(img * p.od[0] + oz) * p.od[1] + oy) * p.od[2] + ox;
@@ -279,6 +298,69 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 // ---------------------------------------------------------------------------------
 // forward / dgrad, two-dimensional unit-stride specialisation
 // ---------------------------------------------------------------------------------
+// ---- contraction split: finishing pass --------------------------------------------------------------------------
+// out[pixel][ch] = sum_split partial[split][pixel][ch] (+ bias) (+ addend), stored in the activation type to one or
+// two destinations, plus the per-(image, channel) statistics.  Thread = (pixel row, four channels).
+template <class TR>
+__global__ __launch_bounds__(256) void ksplit_finish_kernel(const IgemmParams p, int npix_img) {
+    constexpr int ESZ = TR::ESZ;
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [256][8] statistics partials
+    const int img = blockIdx.y;
+    const int cv_n = p.N / 4;
+    const int rows = 256 / cv_n;
+    const int cv = threadIdx.x % cv_n, prow = threadIdx.x / cv_n;
+    const int ch = cv * 4;
+    const size_t npo = (size_t)p.nb * npix_img;
+    const int ppb = (npix_img + gridDim.x - 1) / gridDim.x;
+    const int pbeg = blockIdx.x * ppb, pend = min(npix_img, pbeg + ppb);
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (prow < rows)
+        for (int pix = pbeg + prow; pix < pend; pix += rows) {
+            const size_t op = (size_t)img * npix_img + pix;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int ks = 0; ks < p.ksplit; ++ks) {
+                const float4 t = *reinterpret_cast<const float4*>(p.kpart + ((size_t)ks * npo + op) * p.N + ch);
+                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+            }
+            if (p.stats && ch < p.nstat) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
+            }
+            if (p.bias && ch >= p.bias_c0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += p.bias[ch - p.bias_c0 + j];
+            }
+            if (p.addend) {
+                float a[4];
+                load_n<TR, 4>(p.addend + (op * p.add_pitch + p.add_coff + ch) * ESZ, a);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += a[j];
+            }
+            char* dst = ch < p.out0_c ? p.out + (op * p.out_pitch + p.out_coff + ch) * ESZ
+                                      : p.out1 + (op * p.out1_pitch + p.out1_coff + ch - p.out0_c) * ESZ;
+            store_n<TR, 4>(dst, v);
+        }
+    if (p.stats) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sm[threadIdx.x * 8 + j] = s1[j]; sm[threadIdx.x * 8 + 4 + j] = s2[j]; }
+        __syncthreads();
+        for (int n = rows; n > 1;) {      // fixed-shape tree over the pixel rows
+            const int half = (n + 1) >> 1;
+            if (prow + half < n && prow < rows) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sm[threadIdx.x * 8 + e] += sm[(threadIdx.x + half * cv_n) * 8 + e];
+            }
+            __syncthreads();
+            n = half;
+        }
+        const int slot = blockIdx.x % MI_NSLOT;
+        for (int i = threadIdx.x; i < 2 * p.nstat; i += 256) {
+            const int c = i >> 1, kk = i & 1;
+            atomicAdd(&p.stats[(((size_t)img * MI_NSLOT + slot) * p.stats_c + c) * 2 + kk], (double)sm[(c / 4) * 8 + kk * 4 + (c & 3)]);
+        }
+    }
+}
+
 // sum over the 16 lanes of a DPP row (lanes that share lane >> 4); lane 0 of the row adds in a fixed order
 __device__ __forceinline__ float row_sum16(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
@@ -962,7 +1044,7 @@ int launch_igemm_t(const IgemmParams& pin, hipStream_t st) {
     if (lds < (size_t)NFRAG * 16 * 2 * 4 * 4) lds = NFRAG * 16 * 2 * 4 * 4;
     auto kern = igemm_kernel<TR, CPS, NFRAG>;
     if (int r = set_lds(kern, lds)) return r;
-    dim3 grid(p.nb * p.ntile[0] * p.ntile[1] * p.ntile[2], p.N / (NFRAG * 16), p.nphase);
+    dim3 grid(p.nb * p.ntile[0] * p.ntile[1] * p.ntile[2], p.N / (NFRAG * 16), p.nphase * (p.ksplit > 1 ? p.ksplit : 1));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { mi_set_error(std::string("igemm launch: ") + hipGetErrorString(e)); return -2; }
@@ -1086,7 +1168,8 @@ int launch_igemm(int dtype, const IgemmParams& p, hipStream_t st) {
     MI_CHECK(igemm_lds_for(p, cps, nfrag) <= 160 * 1024, "LDS images do not fit");
     MI_CHECK((long long)p.nb * p.od[0] * p.od[1] * p.od[2] < (1ll << 31) && (long long)p.nb * p.id[0] * p.id[1] * p.id[2] < (1ll << 31),
              "tensor has too many pixels for 32-bit pixel indices");
-    const int ks = getenv("MI_NO_IGEMM2D") ? 0 : igemm2d_ks(p);
+    MI_CHECK(p.ksplit <= 1 || (p.kpart != nullptr && p.N % 4 == 0 && p.N / 4 <= 256), "contraction split needs a partial-sum buffer");
+    const int ks = (getenv("MI_NO_IGEMM2D") || p.ksplit > 1) ? 0 : igemm2d_ks(p);
     int phl_max = 2;   // widest channel tile (in 16-channel fragments) that loops over the scatter phases in one workgroup
     if (const char* e = getenv("MI_PHL_MAX")) phl_max = atoi(e);
 #define IG_CASE(TRT, C, NF)                                                  \
@@ -1178,6 +1261,31 @@ int launch_wgrad(int dtype, const WgradParams& p, hipStream_t st) {
 #undef WG_CASE
     mi_set_error("launch_wgrad: no kernel variant");
     return -1;
+}
+
+// Workgroups the forward / dgrad launch of `p` would use without a contraction split, and its contraction chunks
+void igemm_parallelism(int dtype, const IgemmParams& p, long long* wgs, int* nkc) {
+    int cps, nfrag;
+    igemm_config(dtype, p, &cps, &nfrag);
+    *wgs = (long long)p.nb * p.ntile[0] * p.ntile[1] * p.ntile[2] * p.nphase * (p.N / (16 * nfrag));
+    const int kce = cps * 16 / (dtype ? 2 : 4);
+    *nkc = (p.K + kce - 1) / kce;
+}
+
+int launch_ksplit_finish(int dtype, const IgemmParams& pin, hipStream_t st) {
+    IgemmParams p = pin;
+    if (!p.out1) p.out0_c = p.N;
+    const int npix_img = p.od[0] * p.od[1] * p.od[2];
+    const int rows = 256 / (p.N / 4);
+    int gx = (npix_img + rows * 4 - 1) / (rows * 4);
+    if (gx < 1) gx = 1;
+    if (gx > 1024) gx = 1024;
+    const size_t lds = 256 * 8 * sizeof(float);
+    if (dtype) hipLaunchKernelGGL(ksplit_finish_kernel<BF16>, dim3(gx, p.nb), dim3(256), lds, st, p, npix_img);
+    else hipLaunchKernelGGL(ksplit_finish_kernel<F32>, dim3(gx, p.nb), dim3(256), lds, st, p, npix_img);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { mi_set_error(std::string("ksplit finish launch: ") + hipGetErrorString(e)); return -2; }
+    return 0;
 }
 
 int launch_reduce(const ReduceDesc* d_descs, int ndesc, int max_elems, hipStream_t st) {

@@ -35,6 +35,8 @@ struct IgemmParams {
     int tap_off[MI_MAX_TAPS];               // LDS patch pixel offset of each tap
     int tapg;                               // taps staged per weight tile (<= 9)
     unsigned mg_pd2, mg_pd12;               // reciprocals of pd[2] and pd[1]*pd[2], filled in by the launcher
+    int ksplit; float* kpart;               // > 1: the contraction chunks are split over ksplit workgroups that write raw fp32
+                                            // partial sums [ksplit][output pixel][N] to kpart; launch_ksplit_finish completes the layer
     int tpw;                                // 2-D specialisation: consecutive tiles per workgroup, filled in by the launcher
 };
 
@@ -127,6 +129,8 @@ int launch_reduce(const ReduceDesc* d_descs, int ndesc, int max_elems, hipStream
 int launch_pack(int dtype, const PackDesc* d_descs, int ndesc, int max_elems, hipStream_t st);
 int launch_reduce_one(const ReduceDesc& d, hipStream_t st);
 int c1_wgrad_slabs(int N, const int cd[3]);
+void igemm_parallelism(int dtype, const IgemmParams& p, long long* wgs, int* nkc);
+int launch_ksplit_finish(int dtype, const IgemmParams& p, hipStream_t st);
 void wgrad_choose_split(int dtype, WgradParams& p);
 int launch_pack_one(int dtype, const PackDesc& d, hipStream_t st);
 int launch_norm_fwd(int dtype, const NormParams& p, hipStream_t st);
