@@ -51,14 +51,15 @@ def synthetic_batch(nb, sp, seed, device):
     return x.to(device), t.to(device)
 
 
-def cpu_baseline(budget_s=15.0):
+def cpu_baseline(budget_s=15.0, dropout=0.1):
     """The CPU oracle (plain torch restatement of the reference path) on BASELINE.json configs[0]:
     2-D 16-256 U-Net, fp32, batch 8 of 256x256, forward + DiceCE loss + backward + AdamW."""
     import oracle
 
     threads = torch.get_num_threads()
     torch.manual_seed(0)
-    model = oracle.UNet(2, 1, 1, (16, 32, 64, 128, 256), (2, 2, 2, 2), num_res_units=2, dropout=0.0)
+    model = oracle.UNet(2, 1, 1, (16, 32, 64, 128, 256), (2, 2, 2, 2), num_res_units=2, dropout=dropout)
+    model.train()
     loss = oracle.DiceCELoss(to_onehot_y=False, sigmoid=True)
     opt = torch.optim.AdamW(model.parameters(), lr=5e-4)
     x, t = synthetic_batch(8, (256, 256), 1234, "cpu")
@@ -106,7 +107,7 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--dims", type=int, default=2, choices=(2, 3))
     ap.add_argument("--dtype", default="bf16", choices=("bf16", "fp32"))
-    ap.add_argument("--dropout", type=float, default=0.0)
+    ap.add_argument("--dropout", type=float, default=0.1, help="reference/train.py:85 trains with 0.1")
     ap.add_argument("--channels", default="16,32,64,128,256")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -299,7 +300,7 @@ def main():
         out["roofline"] = roof
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+        out["cpu_baseline"] = cpu_baseline(dropout=args.dropout)
 
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -162,6 +162,40 @@ def test_dropout_statistics_and_mask_replay(dev):
     assert torch.equal(y, y_again)
     y_other = ops.instnorm_prelu_fwd(xc, stats, alpha, dropout=p, seed=43, layer=3)
     assert not torch.equal(y, y_other)
+    y_layer = ops.instnorm_prelu_fwd(xc, stats, alpha, dropout=p, seed=42, layer=4)
+    assert not torch.equal(y, y_layer)
     dy = torch.ones_like(xc)
     dx, _ = ops.instnorm_prelu_bwd(dy, xc, stats, alpha, dropout=p, seed=42, layer=3)
     assert torch.isfinite(dx).all()
+    # the mask is a property of the element index: bf16 storage draws the same one
+    yb = ops.instnorm_prelu_fwd(to_cl(x, torch.bfloat16, dev), stats, alpha, dropout=p, seed=42, layer=3)
+    assert torch.equal(yb == 0, dropped)
+    # every image, channel and position of the four-element hash group drops at the same rate, and
+    # neighbours are uncorrelated
+    m = from_cl(dropped.float())                     # [nb, c, h, w]
+    assert (m.mean(dim=(1, 2, 3)) - p).abs().max() < 0.01
+    assert (m.mean(dim=(0, 2, 3)) - p).abs().max() < 0.02
+    assert not torch.equal(m[0], m[1])
+    for a, b in ((m[:, :-1], m[:, 1:]), (m[..., :-1], m[..., 1:]), (m[:, :, :-1], m[:, :, 1:]), (m[:, 0::4], m[:, 2::4])):
+        cov = float((a * b).mean() - a.mean() * b.mean())
+        assert abs(cov) < 2e-3, cov
+
+
+def test_dropout_rate_follows_probability(dev):
+    nb, c, sp = 1, 16, (128, 128)
+    x = torch.randn(nb, c, *sp, generator=torch.Generator().manual_seed(6))
+    stats = torch.zeros(nb, 8, c, 2, dtype=torch.float64)
+    stats[:, 0, :, 0], stats[:, 0, :, 1] = x.flatten(2).sum(-1), (x * x).flatten(2).sum(-1)
+    stats = stats.to(dev)
+    alpha = torch.tensor([0.25], device=dev)
+    xc = to_cl(x, torch.float32, dev)
+    for p in (0.02, 0.1, 0.5, 0.9):
+        y = ops.instnorm_prelu_fwd(xc, stats, alpha, dropout=p, seed=7, layer=0)
+        frac = float((y == 0).float().mean())
+        assert abs(frac - p) < 0.01, (p, frac)
+    # one-channel planar tensors use the same generator
+    x1 = torch.randn(2, 1, 128, 128, generator=torch.Generator().manual_seed(8))
+    st1 = torch.zeros(2, 8, 1, 2, dtype=torch.float64)
+    st1[:, 0, :, 0], st1[:, 0, :, 1] = x1.flatten(2).sum(-1), (x1 * x1).flatten(2).sum(-1)
+    y1 = ops.instnorm_prelu_fwd(x1.to(dev).reshape(2, 128, 128, 1), st1.to(dev), alpha, dropout=0.1, seed=7, layer=0)
+    assert abs(float((y1 == 0).float().mean()) - 0.1) < 0.01

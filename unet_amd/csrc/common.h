@@ -129,18 +129,41 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // ---- counter-based dropout RNG ----------------------------------------------
-// Keep/drop decision for element `idx` of layer `layer` under `seed`: a 32-bit
-// integer hash compared against a threshold.  Stateless, so backward recomputes
-// the very same mask instead of storing it.
+// Stateless, so backward recomputes the very same mask instead of storing it.  The elements of one image
+// are taken in groups of four consecutive indices; a group draws 64 hash bits, 16 per element, from its
+// group number under three keys derived from (seed, layer, image); an element is dropped when its 16 bits
+// are below the threshold (P(drop) = thresh16 / 65536).  One integer multiply per element: these kernels
+// stream at a few VALU slots per byte, and a full hash per element costs more than the memory traffic.
 __device__ __forceinline__ unsigned mix32(unsigned x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;
 }
-__device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned layer, unsigned long long idx,
-                                             unsigned thresh) {
-    unsigned h = mix32((unsigned)idx ^ mix32((unsigned)(idx >> 32) + 0x9e3779b9u * (layer + 1u)));
-    h = mix32(h ^ (unsigned)seed ^ mix32((unsigned)(seed >> 32) + layer));
-    return h >= thresh;  // P(drop) = thresh / 2^32
+struct DropKeys { unsigned k0, k1, k2, cut; };   // cut = thresh16 << 16
+__device__ __forceinline__ DropKeys dropout_keys(unsigned long long seed, unsigned layer, unsigned img, unsigned thresh16) {
+    unsigned a = mix32((unsigned)seed + 0x9e3779b9u);
+    a = mix32(a ^ (unsigned)(seed >> 32));
+    a = mix32(a ^ layer);
+    a = mix32(a ^ img);
+    DropKeys k;
+    k.k0 = a; k.k1 = mix32(a ^ 0x5bd1e995u); k.k2 = mix32(a ^ 0xc2b2ae35u);
+    k.cut = thresh16 << 16;
+    return k;
+}
+// keep[j] for the elements 4*g + j, j = 0..3, of the image
+__device__ __forceinline__ void dropout_keep4(const DropKeys& k, unsigned g, bool* keep) {
+    unsigned y = g ^ k.k0;
+    y ^= y >> 16; y *= 0x7feb352du;
+    unsigned a = y + k.k1, b = y + k.k2;
+    a ^= a >> 15; a *= 0x846ca68bu; a ^= a >> 16;
+    b ^= b >> 15; b *= 0x735a2d97u; b ^= b >> 15;
+    keep[0] = (a << 16) >= k.cut; keep[1] = a >= k.cut;
+    keep[2] = (b << 16) >= k.cut; keep[3] = b >= k.cut;
+}
+__device__ __forceinline__ bool dropout_keep1(const DropKeys& k, unsigned idx) {
+    bool keep[4];
+    dropout_keep4(k, idx >> 2, keep);
+    const unsigned j = idx & 3u;
+    return j == 0 ? keep[0] : j == 1 ? keep[1] : j == 2 ? keep[2] : keep[3];
 }
 
 // ---- host side ----------------------------------------------------------------

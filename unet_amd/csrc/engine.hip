@@ -951,11 +951,7 @@ int run_step(mi_unet& u, Step& s, char* const* bases, int training, uint64_t see
         case K_NORM_BWD: {
             NormParams p = resolve(s, s.nm, bases);
             p.seed = seed;
-            if (training && u.cfg.dropout > 0.f) {
-                double t = (double)u.cfg.dropout * 4294967296.0;
-                p.drop_thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
-                p.drop_scale = 1.0f / (1.0f - u.cfg.dropout);
-            } else { p.drop_thresh = 0; p.drop_scale = 1.f; }
+            norm_set_dropout(p, training ? u.cfg.dropout : 0.f);
             return s.kind == K_NORM_FWD ? launch_norm_fwd(s.dtype, p, st) : launch_norm_bwd(s.dtype, p, st);
         }
         case K_C1_FWD: return launch_c1_s2_fwd(s.dtype, resolve(s, s.c1, bases), st);

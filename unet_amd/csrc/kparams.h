@@ -88,8 +88,17 @@ struct NormParams {
     int dalpha_slots;                       // 0: atomicAdd into dalpha[0]; 1: dalpha[img*gridDim.x + blockIdx.x] = partial
     int nb, npix, c;
     float eps;
-    unsigned long long seed; unsigned layer, drop_thresh; float drop_scale;  // drop_thresh==0: no dropout
+    unsigned long long seed; unsigned layer, drop_thresh; float drop_scale;  // drop_thresh: P(drop) * 65536, 0 = no dropout
 };
+// dropout probability -> 16-bit threshold and survivor scale of NormParams
+inline void norm_set_dropout(NormParams& p, float dropout) {
+    if (dropout > 0.f) {
+        long t = (long)((double)dropout * 65536.0 + 0.5);
+        p.drop_thresh = t < 1 ? 1u : t > 65535 ? 65535u : (unsigned)t;
+        p.drop_scale = 1.0f / (1.0f - dropout);
+    } else { p.drop_thresh = 0; p.drop_scale = 1.f; }
+}
+
 
 
 // One-channel <-> N-channel stride-2 kernels (first encoder conv, last decoder transposed conv)

@@ -61,6 +61,8 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const NormParams p) {
     const NormLane l = norm_lane<VEC>(p);
     if (!l.active) return;
     const float alpha = *p.alpha;
+    const DropKeys dk = dropout_keys(p.seed, p.layer, img, p.drop_thresh);
+    const unsigned cq = p.c / 4, gq = l.ch0 / 4;    // dropout groups per pixel, first group of this lane
     float mean[VEC], rstd[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { mean[e] = sm[(l.ch0 + e) * 2]; rstd[e] = sm[(l.ch0 + e) * 2 + 1]; }
@@ -84,13 +86,15 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const NormParams p) {
             const int pix = pix0 + u * l.rows;
             if (pix < l.pend) {
                 float o[VEC];
+                bool keep[VEC];
+                if (p.drop_thresh) {
+#pragma unroll
+                    for (int q = 0; q < VEC / 4; ++q) dropout_keep4(dk, (unsigned)pix * cq + gq + q, keep + 4 * q);
+                }
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
                     float d = (x[u][e] - mean[e]) * rstd[e];
-                    if (p.drop_thresh) {
-                        const bool keep = dropout_keep(p.seed, p.layer, (unsigned long long)(img_pix + pix) * p.c + l.ch0 + e, p.drop_thresh);
-                        d = keep ? d * p.drop_scale : 0.f;
-                    }
+                    if (p.drop_thresh) d = keep[e] ? d * p.drop_scale : 0.f;
                     float y = d > 0.f ? d : alpha * d;
                     if (rb) y += r[u][e];
                     o[e] = y;
@@ -120,6 +124,8 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const NormParams p
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
     if (l.active) {
+        const DropKeys dk = dropout_keys(p.seed, p.layer, img, p.drop_thresh);
+        const unsigned cq = p.c / 4, gq = l.ch0 / 4;
         float mean[VEC], rstd[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) { mean[e] = sm[(l.ch0 + e) * 2]; rstd[e] = sm[(l.ch0 + e) * 2 + 1]; }
@@ -141,14 +147,17 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const NormParams p
             for (int u = 0; u < NORM_U; ++u) {
                 const int pix = pix0 + u * l.rows;
                 if (pix < l.pend) {
+                    bool keep[VEC];
+                    if (p.drop_thresh) {
+#pragma unroll
+                        for (int q = 0; q < VEC / 4; ++q) dropout_keep4(dk, (unsigned)pix * cq + gq + q, keep + 4 * q);
+                    }
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) {
                         const float xh = (x[u][e] - mean[e]) * rstd[e];
                         float d = xh, sc = 1.f;
                         if (p.drop_thresh) {
-                            const bool keep = dropout_keep(p.seed, p.layer, (unsigned long long)(img_pix + pix) * p.c + l.ch0 + e,
-                                                           p.drop_thresh);
-                            sc = keep ? p.drop_scale : 0.f;
+                            sc = keep[e] ? p.drop_scale : 0.f;
                             d = xh * sc;
                         }
                         const float gd = dy[u][e] * (d > 0.f ? 1.f : alpha);
@@ -209,6 +218,8 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const NormParams p)
     const NormLane l = norm_lane<VEC>(p);
     if (!l.active) return;
     const float alpha = *p.alpha;
+    const DropKeys dk = dropout_keys(p.seed, p.layer, img, p.drop_thresh);
+    const unsigned cq = p.c / 4, gq = l.ch0 / 4;
     float mean[VEC], rstd[VEC], b1[VEC], b2[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
@@ -235,13 +246,17 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const NormParams p)
             const int pix = pix0 + u * l.rows;
             if (pix < l.pend) {
                 float o[VEC];
+                bool keep[VEC];
+                if (p.drop_thresh) {
+#pragma unroll
+                    for (int q = 0; q < VEC / 4; ++q) dropout_keep4(dk, (unsigned)pix * cq + gq + q, keep + 4 * q);
+                }
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
                     const float xh = (x[u][e] - mean[e]) * rstd[e];
                     float d = xh, sc = 1.f;
                     if (p.drop_thresh) {
-                        const bool keep = dropout_keep(p.seed, p.layer, (unsigned long long)(img_pix + pix) * p.c + l.ch0 + e, p.drop_thresh);
-                        sc = keep ? p.drop_scale : 0.f;
+                        sc = keep[e] ? p.drop_scale : 0.f;
                         d = xh * sc;
                     }
                     const float gh = dy[u][e] * (d > 0.f ? 1.f : alpha) * sc;
@@ -274,12 +289,13 @@ __global__ __launch_bounds__(256) void norm1_fwd_kernel(const NormParams p) {
     float mean, rstd;
     c1_moments(p.stats, img, p.npix, p.eps, mean, rstd);
     const float alpha = *p.alpha;
+    const DropKeys dk = dropout_keys(p.seed, p.layer, img, p.drop_thresh);
     const float* x = reinterpret_cast<const float*>(p.x) + (size_t)img * p.npix;
     float* out = reinterpret_cast<float*>(p.out) + (size_t)img * p.npix;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < p.npix; i += gridDim.x * 256) {
         float d = (x[i] - mean) * rstd;
         if (p.drop_thresh) {
-            const bool keep = dropout_keep(p.seed, p.layer, (unsigned long long)img * p.npix + i, p.drop_thresh);
+            const bool keep = dropout_keep1(dk, (unsigned)i);
             d = keep ? d * p.drop_scale : 0.f;
         }
         out[i] = d > 0.f ? d : alpha * d;
@@ -292,6 +308,7 @@ __global__ __launch_bounds__(256) void norm1_bwd_reduce_kernel(const NormParams 
     float mean, rstd;
     c1_moments(p.stats, img, p.npix, p.eps, mean, rstd);
     const float alpha = *p.alpha;
+    const DropKeys dk = dropout_keys(p.seed, p.layer, img, p.drop_thresh);
     const float* x = reinterpret_cast<const float*>(p.x) + (size_t)img * p.npix;
     const float* dy = reinterpret_cast<const float*>(p.dy) + (size_t)img * p.npix;
     float s1 = 0.f, s2 = 0.f, da = 0.f;
@@ -299,7 +316,7 @@ __global__ __launch_bounds__(256) void norm1_bwd_reduce_kernel(const NormParams 
         const float xh = (x[i] - mean) * rstd;
         float d = xh, sc = 1.f;
         if (p.drop_thresh) {
-            const bool keep = dropout_keep(p.seed, p.layer, (unsigned long long)img * p.npix + i, p.drop_thresh);
+            const bool keep = dropout_keep1(dk, (unsigned)i);
             sc = keep ? p.drop_scale : 0.f;
             d = xh * sc;
         }
@@ -336,6 +353,7 @@ __global__ __launch_bounds__(256) void norm1_bwd_apply_kernel(const NormParams p
     }
     const float b1 = (float)(d1 / (double)p.npix), b2 = (float)(d2 / (double)p.npix);
     const float alpha = *p.alpha;
+    const DropKeys dk = dropout_keys(p.seed, p.layer, img, p.drop_thresh);
     const float* x = reinterpret_cast<const float*>(p.x) + (size_t)img * p.npix;
     const float* dy = reinterpret_cast<const float*>(p.dy) + (size_t)img * p.npix;
     float* out = reinterpret_cast<float*>(p.out) + (size_t)img * p.npix;
@@ -343,7 +361,7 @@ __global__ __launch_bounds__(256) void norm1_bwd_apply_kernel(const NormParams p
         const float xh = (x[i] - mean) * rstd;
         float d = xh, sc = 1.f;
         if (p.drop_thresh) {
-            const bool keep = dropout_keep(p.seed, p.layer, (unsigned long long)img * p.npix + i, p.drop_thresh);
+            const bool keep = dropout_keep1(dk, (unsigned)i);
             sc = keep ? p.drop_scale : 0.f;
             d = xh * sc;
         }
@@ -386,6 +404,7 @@ int norm_bwd_reduce_blocks(int npix, int c) {
 
 // dtype: 0 fp32, 1 bf16.  c == 1 selects the planar fp32 kernels (pitch must be 1, dtype 0).
 int launch_norm_fwd(int dtype, const NormParams& p, hipStream_t st) {
+    MI_CHECK(!p.drop_thresh || (long long)p.npix * p.c < (1ll << 34), "dropout numbers the elements of one image in 34 bits");
     if (p.c == 1) {
         MI_CHECK(dtype == 0 && p.x_pitch == 1 && p.out_pitch == 1 && !p.res, "one-channel tensors are planar fp32");
         int gx = (p.npix + 1023) / 1024; if (gx > 256) gx = 256;
@@ -405,6 +424,7 @@ int launch_norm_fwd(int dtype, const NormParams& p, hipStream_t st) {
 
 // bstats ([nb][NSLOT][c][2] doubles) must be zero on entry; dalpha is accumulated into.
 int launch_norm_bwd(int dtype, const NormParams& p, hipStream_t st) {
+    MI_CHECK(!p.drop_thresh || (long long)p.npix * p.c < (1ll << 34), "dropout numbers the elements of one image in 34 bits");
     if (p.c == 1) {
         MI_CHECK(dtype == 0 && p.x_pitch == 1 && p.out_pitch == 1 && p.dy_pitch == 1, "one-channel tensors are planar fp32");
         const int gx = norm_bwd_reduce_blocks(p.npix, 1);

@@ -133,11 +133,7 @@ int mi_conv_wgrad(const mi_conv_desc* d, const mi_tensor* x, const mi_tensor* dy
 
 static void fill_drop(NormParams& p, float dropout, uint64_t seed, uint32_t layer) {
     p.seed = seed; p.layer = layer;
-    if (dropout > 0.f) {
-        double t = (double)dropout * 4294967296.0;
-        p.drop_thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
-        p.drop_scale = 1.0f / (1.0f - dropout);
-    } else { p.drop_thresh = 0; p.drop_scale = 1.f; }
+    norm_set_dropout(p, dropout);
 }
 
 int mi_instnorm_prelu_fwd(int dtype, int nb, int64_t npix, int c, const mi_tensor* raw, const double* stats,
