@@ -28,7 +28,14 @@ __device__ __forceinline__ void load_moments(const double* stats, int img, int c
     }
 }
 
-constexpr int NORM_U = 4;      // independent 16-byte loads in flight per thread and tensor
+#ifndef NORM_U_N
+#define NORM_U_N 4
+#endif
+constexpr int NORM_U = NORM_U_N;      // independent 16-byte loads in flight per thread and tensor (forward)
+#ifndef NORM_UB_N
+#define NORM_UB_N 2
+#endif
+constexpr int NORM_UB = NORM_UB_N;   // the same for the backward kernels (two input tensors)
 
 // Thread layout shared by the three kernels: cv_n = 16-byte vectors per pixel, a sweep of the workgroup
 // covers rows = 256 / cv_n pixels, thread (prow, cv) keeps the same channel group for all its pixels, so
@@ -51,7 +58,51 @@ __device__ __forceinline__ NormLane norm_lane(const NormParams& p) {
     return l;
 }
 
-template <class TR>
+// Sums the per-thread partials s[2*VEC] (sums of gh, then of gh*xh, for the thread's VEC channels) over all pixel
+// rows of the workgroup; on return part[ccv * 2*VEC + e] holds the totals of channel vector ccv (after the final
+// barrier).  Threads of one channel vector sit cv_n lanes apart: when cv_n is a power of two that fits a wave, the
+// rows inside a wave are folded with lane exchanges and only one value set per wave goes through LDS (one
+// barrier instead of one per tree level); other channel counts use a fixed-shape LDS tree.  Both orders are fixed.
+template <int VEC>
+__device__ __forceinline__ void sum_rows(float* s, float* part, const NormLane& l, int cv_n) {
+    constexpr int W = 2 * VEC;
+    if ((cv_n & (cv_n - 1)) == 0 && cv_n <= 64 && cv_n >= 8) {     // at most three exchange steps; below that the tree is cheaper
+        for (int o = 32; o >= cv_n; o >>= 1) {
+#pragma unroll
+            for (int e = 0; e < W; ++e) s[e] += __shfl_xor(s[e], o, 64);
+        }
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        if (lane < cv_n) {
+#pragma unroll
+            for (int e = 0; e < W; ++e) part[(w * cv_n + lane) * W + e] = s[e];
+        }
+        __syncthreads();
+        const int n = cv_n * W;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const float tot = ((part[i] + part[i + n]) + part[i + 2 * n]) + part[i + 3 * n];
+            part[i] = tot;                                   // column i is touched by this thread only
+        }
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int e = 0; e < W; ++e) part[threadIdx.x * W + e] = s[e];
+        __syncthreads();
+        for (int n = l.rows; n > 1;) {
+            const int half = (n + 1) >> 1;
+            if (l.prow + half < n) {
+#pragma unroll
+                for (int e = 0; e < W; ++e) part[threadIdx.x * W + e] += part[(threadIdx.x + half * cv_n) * W + e];
+            }
+            __syncthreads();
+            n = half;
+        }
+    }
+}
+
+// The three streaming kernels below share one shape: a thread walks its pixels NORM_U at a time, all loads of a
+// step are issued before the first use, full steps carry no bounds checks (a short tail loop takes the rest),
+// and dropout / residual are compile-time switches, so the inner loops are straight-line code.
+template <class TR, bool DROP, bool RES>
 __global__ __launch_bounds__(256) void norm_fwd_kernel(const NormParams p) {
     constexpr int VEC = TR::VEC, ESZ = TR::ESZ;
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -63,53 +114,58 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const NormParams p) {
     const float alpha = *p.alpha;
     const DropKeys dk = dropout_keys(p.seed, p.layer, img, p.drop_thresh);
     const unsigned cq = p.c / 4, gq = l.ch0 / 4;    // dropout groups per pixel, first group of this lane
+    const float scale = p.drop_scale;
     float mean[VEC], rstd[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { mean[e] = sm[(l.ch0 + e) * 2]; rstd[e] = sm[(l.ch0 + e) * 2 + 1]; }
     const size_t img_pix = (size_t)img * p.npix;
-    const char* xb = p.x + (img_pix * p.x_pitch + p.x_coff + l.ch0) * ESZ;
-    const char* rb = p.res ? p.res + (img_pix * p.res_pitch + p.res_coff + l.ch0) * ESZ : nullptr;
-    char* ob = p.out + (img_pix * p.out_pitch + p.out_coff + l.ch0) * ESZ;
-    const size_t xs = (size_t)p.x_pitch * ESZ, rs = (size_t)p.res_pitch * ESZ, os = (size_t)p.out_pitch * ESZ;
-    for (int pix0 = l.pbeg + l.prow; pix0 < l.pend; pix0 += l.rows * NORM_U) {
-        float x[NORM_U][VEC], r[NORM_U][VEC];
+    const char* xb = p.x + (img_pix * p.x_pitch + p.x_coff) * ESZ;
+    const char* rb = RES ? p.res + (img_pix * p.res_pitch + p.res_coff) * ESZ : nullptr;
+    char* ob = p.out + (img_pix * p.out_pitch + p.out_coff) * ESZ;
+    const unsigned xs = p.x_pitch * ESZ, rs = p.res_pitch * ESZ, os = p.out_pitch * ESZ, cb = l.ch0 * ESZ;   // 32-bit offsets inside one image
+    auto unit = [&](const uint4& xr, const uint4& rr, int pix) {
+        float x[VEC], r[VEC], o[VEC];
+        bool keep[VEC];
+        unpack_vec<TR>(xr, x);
+        if (RES) unpack_vec<TR>(rr, r);
+        if (DROP) {
+#pragma unroll
+            for (int q = 0; q < VEC / 4; ++q) dropout_keep4(dk, (unsigned)pix * cq + gq + q, keep + 4 * q);
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            float d = (x[e] - mean[e]) * rstd[e];
+            if (DROP) d = keep[e] ? d * scale : 0.f;
+            float y = d > 0.f ? d : alpha * d;
+            if (RES) y += r[e];
+            o[e] = y;
+        }
+        store_vec<TR>(ob + ((unsigned)pix * os + cb), o);
+    };
+    int pix0 = l.pbeg + l.prow;
+    for (; pix0 + (NORM_U - 1) * l.rows < l.pend; pix0 += l.rows * NORM_U) {
+        uint4 xr[NORM_U], rr[NORM_U];
 #pragma unroll
         for (int u = 0; u < NORM_U; ++u) {
             const int pix = pix0 + u * l.rows;
-            if (pix < l.pend) {
-                load_vec<TR>(xb + pix * xs, x[u]);
-                if (rb) load_vec<TR>(rb + pix * rs, r[u]);
-            }
+            xr[u] = *reinterpret_cast<const uint4*>(xb + ((unsigned)pix * xs + cb));
+            if (RES) rr[u] = *reinterpret_cast<const uint4*>(rb + ((unsigned)pix * rs + cb));
         }
 #pragma unroll
-        for (int u = 0; u < NORM_U; ++u) {
-            const int pix = pix0 + u * l.rows;
-            if (pix < l.pend) {
-                float o[VEC];
-                bool keep[VEC];
-                if (p.drop_thresh) {
-#pragma unroll
-                    for (int q = 0; q < VEC / 4; ++q) dropout_keep4(dk, (unsigned)pix * cq + gq + q, keep + 4 * q);
-                }
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    float d = (x[u][e] - mean[e]) * rstd[e];
-                    if (p.drop_thresh) d = keep[e] ? d * p.drop_scale : 0.f;
-                    float y = d > 0.f ? d : alpha * d;
-                    if (rb) y += r[u][e];
-                    o[e] = y;
-                }
-                store_vec<TR>(ob + pix * os, o);
-            }
-        }
+        for (int u = 0; u < NORM_U; ++u) { unit(xr[u], rr[u], pix0 + u * l.rows); __builtin_amdgcn_sched_barrier(0); }
+    }
+    for (; pix0 < l.pend; pix0 += l.rows) {
+        uint4 xr = *reinterpret_cast<const uint4*>(xb + ((unsigned)pix0 * xs + cb)), rr = xr;
+        if (RES) rr = *reinterpret_cast<const uint4*>(rb + ((unsigned)pix0 * rs + cb));
+        unit(xr, rr, pix0);
     }
 }
 
 // backward pass 1: per-(image, channel) sums of gh and gh*xh, and the slope gradient.
-// Reduction order is fixed inside a workgroup (per-thread partials in LDS, summed row by row);
+// Reduction order is fixed inside a workgroup (per-thread partials, then sum_rows);
 // workgroup sums go to fp64 accumulators.
-template <class TR>
-__global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const NormParams p) {
+template <class TR, bool DROP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void norm_bwd_reduce_kernel(const NormParams p) {
     constexpr int VEC = TR::VEC, ESZ = TR::ESZ;
     extern __shared__ __attribute__((aligned(16))) float sm[];  // [c][2] moments, then [256][2*VEC] partials
     __shared__ float red_da[4];
@@ -120,73 +176,58 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const NormParams p
     const NormLane l = norm_lane<VEC>(p);
     const int cv_n = p.c / VEC;
     const float alpha = *p.alpha;
-    float s1[VEC], s2[VEC], da = 0.f;
+    float s12[2 * VEC], da = 0.f;
+    float* const s1 = s12; float* const s2 = s12 + VEC;
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    for (int e = 0; e < 2 * VEC; ++e) s12[e] = 0.f;
     if (l.active) {
         const DropKeys dk = dropout_keys(p.seed, p.layer, img, p.drop_thresh);
         const unsigned cq = p.c / 4, gq = l.ch0 / 4;
+        const float scale = p.drop_scale;
         float mean[VEC], rstd[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) { mean[e] = sm[(l.ch0 + e) * 2]; rstd[e] = sm[(l.ch0 + e) * 2 + 1]; }
         const size_t img_pix = (size_t)img * p.npix;
-        const char* xb = p.x + (img_pix * p.x_pitch + p.x_coff + l.ch0) * ESZ;
-        const char* gb = p.dy + (img_pix * p.dy_pitch + p.dy_coff + l.ch0) * ESZ;
-        const size_t xs = (size_t)p.x_pitch * ESZ, gs = (size_t)p.dy_pitch * ESZ;
-        for (int pix0 = l.pbeg + l.prow; pix0 < l.pend; pix0 += l.rows * NORM_U) {
-            float x[NORM_U][VEC], dy[NORM_U][VEC];
+        const char* xb = p.x + (img_pix * p.x_pitch + p.x_coff) * ESZ;
+        const char* gb = p.dy + (img_pix * p.dy_pitch + p.dy_coff) * ESZ;
+        const unsigned xs = p.x_pitch * ESZ, gs = p.dy_pitch * ESZ, cb = l.ch0 * ESZ;
+        auto unit = [&](const uint4& xr, const uint4& gr, int pix) {
+            float x[VEC], dy[VEC];
+            bool keep[VEC];
+            unpack_vec<TR>(xr, x); unpack_vec<TR>(gr, dy);
+            if (DROP) {
 #pragma unroll
-            for (int u = 0; u < NORM_U; ++u) {
-                const int pix = pix0 + u * l.rows;
-                if (pix < l.pend) {
-                    load_vec<TR>(xb + pix * xs, x[u]);
-                    load_vec<TR>(gb + pix * gs, dy[u]);
-                }
+                for (int q = 0; q < VEC / 4; ++q) dropout_keep4(dk, (unsigned)pix * cq + gq + q, keep + 4 * q);
             }
 #pragma unroll
-            for (int u = 0; u < NORM_U; ++u) {
-                const int pix = pix0 + u * l.rows;
-                if (pix < l.pend) {
-                    bool keep[VEC];
-                    if (p.drop_thresh) {
-#pragma unroll
-                        for (int q = 0; q < VEC / 4; ++q) dropout_keep4(dk, (unsigned)pix * cq + gq + q, keep + 4 * q);
-                    }
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) {
-                        const float xh = (x[u][e] - mean[e]) * rstd[e];
-                        float d = xh, sc = 1.f;
-                        if (p.drop_thresh) {
-                            sc = keep[e] ? p.drop_scale : 0.f;
-                            d = xh * sc;
-                        }
-                        const float gd = dy[u][e] * (d > 0.f ? 1.f : alpha);
-                        da += dy[u][e] * fminf(d, 0.f);
-                        const float gh = gd * sc;
-                        s1[e] += gh; s2[e] += gh * xh;
-                    }
-                }
+            for (int e = 0; e < VEC; ++e) {
+                const float xh = (x[e] - mean[e]) * rstd[e];
+                float d = xh, sc = 1.f;
+                if (DROP) { sc = keep[e] ? scale : 0.f; d = xh * sc; }
+                const float gd = dy[e] * (d > 0.f ? 1.f : alpha);
+                da += dy[e] * fminf(d, 0.f);
+                const float gh = DROP ? gd * sc : gd;
+                s1[e] += gh; s2[e] += gh * xh;
             }
+        };
+        int pix0 = l.pbeg + l.prow;
+        for (; pix0 + (NORM_UB - 1) * l.rows < l.pend; pix0 += l.rows * NORM_UB) {
+            uint4 xr[NORM_UB], gr[NORM_UB];
+#pragma unroll
+            for (int u = 0; u < NORM_UB; ++u) {
+                const int pix = pix0 + u * l.rows;
+                xr[u] = *reinterpret_cast<const uint4*>(xb + ((unsigned)pix * xs + cb));
+                gr[u] = *reinterpret_cast<const uint4*>(gb + ((unsigned)pix * gs + cb));
+            }
+#pragma unroll
+            for (int u = 0; u < NORM_UB; ++u) { unit(xr[u], gr[u], pix0 + u * l.rows); __builtin_amdgcn_sched_barrier(0); }
         }
-    }
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-        part[threadIdx.x * 2 * VEC + e] = s1[e];
-        part[threadIdx.x * 2 * VEC + VEC + e] = s2[e];
+        for (; pix0 < l.pend; pix0 += l.rows)
+            unit(*reinterpret_cast<const uint4*>(xb + ((unsigned)pix0 * xs + cb)), *reinterpret_cast<const uint4*>(gb + ((unsigned)pix0 * gs + cb)), pix0);
     }
     da = wave_sum(da);
     if ((threadIdx.x & 63) == 0) red_da[threadIdx.x >> 6] = da;
-    __syncthreads();
-    // fixed-shape tree over the pixel rows of the workgroup: row r takes row r + half
-    for (int n = l.rows; n > 1;) {
-        const int half = (n + 1) >> 1;
-        if (l.prow + half < n) {
-#pragma unroll
-            for (int e = 0; e < 2 * VEC; ++e) part[threadIdx.x * 2 * VEC + e] += part[(threadIdx.x + half * cv_n) * 2 * VEC + e];
-        }
-        __syncthreads();
-        n = half;
-    }
+    sum_rows<VEC>(s12, part, l, cv_n);
     const int slot = blockIdx.x % MI_NSLOT;
     for (int i = threadIdx.x; i < 2 * p.c; i += 256) {
         const int ch = i >> 1, k = i & 1;
@@ -201,7 +242,7 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const NormParams p
 }
 
 // backward pass 2: dx
-template <class TR>
+template <class TR, bool DROP>
 __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const NormParams p) {
     constexpr int VEC = TR::VEC, ESZ = TR::ESZ;
     extern __shared__ __attribute__((aligned(16))) float sm[];  // [c][2] moments, [c][2] backward means
@@ -220,6 +261,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const NormParams p)
     const float alpha = *p.alpha;
     const DropKeys dk = dropout_keys(p.seed, p.layer, img, p.drop_thresh);
     const unsigned cq = p.c / 4, gq = l.ch0 / 4;
+    const float scale = p.drop_scale;
     float mean[VEC], rstd[VEC], b1[VEC], b2[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
@@ -227,45 +269,43 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const NormParams p)
         b1[e] = bm[(l.ch0 + e) * 2]; b2[e] = bm[(l.ch0 + e) * 2 + 1];
     }
     const size_t img_pix = (size_t)img * p.npix;
-    const char* xb = p.x + (img_pix * p.x_pitch + p.x_coff + l.ch0) * ESZ;
-    const char* gb = p.dy + (img_pix * p.dy_pitch + p.dy_coff + l.ch0) * ESZ;
-    char* ob = p.out + (img_pix * p.out_pitch + p.out_coff + l.ch0) * ESZ;
-    const size_t xs = (size_t)p.x_pitch * ESZ, gs = (size_t)p.dy_pitch * ESZ, os = (size_t)p.out_pitch * ESZ;
-    for (int pix0 = l.pbeg + l.prow; pix0 < l.pend; pix0 += l.rows * NORM_U) {
-        float x[NORM_U][VEC], dy[NORM_U][VEC];
+    const char* xb = p.x + (img_pix * p.x_pitch + p.x_coff) * ESZ;
+    const char* gb = p.dy + (img_pix * p.dy_pitch + p.dy_coff) * ESZ;
+    char* ob = p.out + (img_pix * p.out_pitch + p.out_coff) * ESZ;
+    const unsigned xs = p.x_pitch * ESZ, gs = p.dy_pitch * ESZ, os = p.out_pitch * ESZ, cb = l.ch0 * ESZ;
+    auto unit = [&](const uint4& xr, const uint4& gr, int pix) {
+        float x[VEC], dy[VEC], o[VEC];
+        bool keep[VEC];
+        unpack_vec<TR>(xr, x); unpack_vec<TR>(gr, dy);
+        if (DROP) {
 #pragma unroll
-        for (int u = 0; u < NORM_U; ++u) {
-            const int pix = pix0 + u * l.rows;
-            if (pix < l.pend) {
-                load_vec<TR>(xb + pix * xs, x[u]);
-                load_vec<TR>(gb + pix * gs, dy[u]);
-            }
+            for (int q = 0; q < VEC / 4; ++q) dropout_keep4(dk, (unsigned)pix * cq + gq + q, keep + 4 * q);
         }
 #pragma unroll
-        for (int u = 0; u < NORM_U; ++u) {
-            const int pix = pix0 + u * l.rows;
-            if (pix < l.pend) {
-                float o[VEC];
-                bool keep[VEC];
-                if (p.drop_thresh) {
-#pragma unroll
-                    for (int q = 0; q < VEC / 4; ++q) dropout_keep4(dk, (unsigned)pix * cq + gq + q, keep + 4 * q);
-                }
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    const float xh = (x[u][e] - mean[e]) * rstd[e];
-                    float d = xh, sc = 1.f;
-                    if (p.drop_thresh) {
-                        sc = keep[e] ? p.drop_scale : 0.f;
-                        d = xh * sc;
-                    }
-                    const float gh = dy[u][e] * (d > 0.f ? 1.f : alpha) * sc;
-                    o[e] = rstd[e] * (gh - b1[e] - xh * b2[e]);
-                }
-                store_vec<TR>(ob + pix * os, o);
-            }
+        for (int e = 0; e < VEC; ++e) {
+            const float xh = (x[e] - mean[e]) * rstd[e];
+            float d = xh, sc = 1.f;
+            if (DROP) { sc = keep[e] ? scale : 0.f; d = xh * sc; }
+            float gh = dy[e] * (d > 0.f ? 1.f : alpha);
+            if (DROP) gh *= sc;
+            o[e] = rstd[e] * (gh - b1[e] - xh * b2[e]);
         }
+        store_vec<TR>(ob + ((unsigned)pix * os + cb), o);
+    };
+    int pix0 = l.pbeg + l.prow;
+    for (; pix0 + (NORM_UB - 1) * l.rows < l.pend; pix0 += l.rows * NORM_UB) {
+        uint4 xr[NORM_UB], gr[NORM_UB];
+#pragma unroll
+        for (int u = 0; u < NORM_UB; ++u) {
+            const int pix = pix0 + u * l.rows;
+            xr[u] = *reinterpret_cast<const uint4*>(xb + ((unsigned)pix * xs + cb));
+            gr[u] = *reinterpret_cast<const uint4*>(gb + ((unsigned)pix * gs + cb));
+        }
+#pragma unroll
+        for (int u = 0; u < NORM_UB; ++u) { unit(xr[u], gr[u], pix0 + u * l.rows); __builtin_amdgcn_sched_barrier(0); }
     }
+    for (; pix0 < l.pend; pix0 += l.rows)
+        unit(*reinterpret_cast<const uint4*>(xb + ((unsigned)pix0 * xs + cb)), *reinterpret_cast<const uint4*>(gb + ((unsigned)pix0 * gs + cb)), pix0);
 }
 
 // ---- one-channel fp32 planar variants (top of the decoder) ------------------------
@@ -404,6 +444,10 @@ int norm_bwd_reduce_blocks(int npix, int c) {
 
 // dtype: 0 fp32, 1 bf16.  c == 1 selects the planar fp32 kernels (pitch must be 1, dtype 0).
 int launch_norm_fwd(int dtype, const NormParams& p, hipStream_t st) {
+    {
+        const long long pm = p.res ? (p.res_pitch > p.x_pitch ? p.res_pitch : p.x_pitch) : p.x_pitch;
+        MI_CHECK((long long)p.npix * (pm > p.out_pitch ? pm : p.out_pitch) * (dtype ? 2 : 4) < (1ll << 32), "one image of a tensor must stay below 4 GiB");
+    }
     MI_CHECK(!p.drop_thresh || (long long)p.npix * p.c < (1ll << 34), "dropout numbers the elements of one image in 34 bits");
     if (p.c == 1) {
         MI_CHECK(dtype == 0 && p.x_pitch == 1 && p.out_pitch == 1 && !p.res, "one-channel tensors are planar fp32");
@@ -417,13 +461,26 @@ int launch_norm_fwd(int dtype, const NormParams& p, hipStream_t st) {
     int gx = norm_blocks(p.npix, p.c, vec, 8, 65535);
     if ((long long)gx * p.nb < 1024) gx = norm_blocks(p.npix, p.c, vec, 4, 65535);   // small tensors: shorter workgroups, more of them
     const size_t lds = (size_t)p.c * 2 * sizeof(float);
-    if (dtype) hipLaunchKernelGGL(norm_fwd_kernel<BF16>, dim3(gx, p.nb), dim3(256), lds, st, p);
-    else hipLaunchKernelGGL(norm_fwd_kernel<F32>, dim3(gx, p.nb), dim3(256), lds, st, p);
+    const dim3 grid(gx, p.nb);
+#define NORM_FWD_CASE(TR, D, R) hipLaunchKernelGGL((norm_fwd_kernel<TR, D, R>), grid, dim3(256), lds, st, p)
+    const bool drop = p.drop_thresh != 0, res = p.res != nullptr;
+    if (dtype) {
+        if (drop) { if (res) NORM_FWD_CASE(BF16, true, true); else NORM_FWD_CASE(BF16, true, false); }
+        else { if (res) NORM_FWD_CASE(BF16, false, true); else NORM_FWD_CASE(BF16, false, false); }
+    } else {
+        if (drop) { if (res) NORM_FWD_CASE(F32, true, true); else NORM_FWD_CASE(F32, true, false); }
+        else { if (res) NORM_FWD_CASE(F32, false, true); else NORM_FWD_CASE(F32, false, false); }
+    }
+#undef NORM_FWD_CASE
     return check_launch("norm_fwd");
 }
 
 // bstats ([nb][NSLOT][c][2] doubles) must be zero on entry; dalpha is accumulated into.
 int launch_norm_bwd(int dtype, const NormParams& p, hipStream_t st) {
+    {
+        const long long pm = p.dy_pitch > p.x_pitch ? p.dy_pitch : p.x_pitch;
+        MI_CHECK((long long)p.npix * (pm > p.out_pitch ? pm : p.out_pitch) * (dtype ? 2 : 4) < (1ll << 32), "one image of a tensor must stay below 4 GiB");
+    }
     MI_CHECK(!p.drop_thresh || (long long)p.npix * p.c < (1ll << 34), "dropout numbers the elements of one image in 34 bits");
     if (p.c == 1) {
         MI_CHECK(dtype == 0 && p.x_pitch == 1 && p.out_pitch == 1 && p.dy_pitch == 1, "one-channel tensors are planar fp32");
@@ -440,12 +497,23 @@ int launch_norm_bwd(int dtype, const NormParams& p, hipStream_t st) {
     const size_t lds = (size_t)p.c * 4 * sizeof(float);
     const size_t lds_r = ((size_t)p.c * 2 + 256 * 2 * vec) * sizeof(float);
     const int gr = norm_bwd_reduce_blocks(p.npix, p.c);
-    if (dtype) hipLaunchKernelGGL(norm_bwd_reduce_kernel<BF16>, dim3(gr, p.nb), dim3(256), lds_r, st, p);
-    else hipLaunchKernelGGL(norm_bwd_reduce_kernel<F32>, dim3(gr, p.nb), dim3(256), lds_r, st, p);
+    const bool drop = p.drop_thresh != 0;
+    if (dtype) {
+        if (drop) hipLaunchKernelGGL((norm_bwd_reduce_kernel<BF16, true>), dim3(gr, p.nb), dim3(256), lds_r, st, p);
+        else hipLaunchKernelGGL((norm_bwd_reduce_kernel<BF16, false>), dim3(gr, p.nb), dim3(256), lds_r, st, p);
+    } else {
+        if (drop) hipLaunchKernelGGL((norm_bwd_reduce_kernel<F32, true>), dim3(gr, p.nb), dim3(256), lds_r, st, p);
+        else hipLaunchKernelGGL((norm_bwd_reduce_kernel<F32, false>), dim3(gr, p.nb), dim3(256), lds_r, st, p);
+    }
     if (int r = check_launch("norm_bwd_reduce")) return r;
     int gx = norm_blocks(p.npix, p.c, vec, 8, 65535);
     if ((long long)gx * p.nb < 1024) gx = norm_blocks(p.npix, p.c, vec, 4, 65535);
-    if (dtype) hipLaunchKernelGGL(norm_bwd_apply_kernel<BF16>, dim3(gx, p.nb), dim3(256), lds, st, p);
-    else hipLaunchKernelGGL(norm_bwd_apply_kernel<F32>, dim3(gx, p.nb), dim3(256), lds, st, p);
+    if (dtype) {
+        if (drop) hipLaunchKernelGGL((norm_bwd_apply_kernel<BF16, true>), dim3(gx, p.nb), dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((norm_bwd_apply_kernel<BF16, false>), dim3(gx, p.nb), dim3(256), lds, st, p);
+    } else {
+        if (drop) hipLaunchKernelGGL((norm_bwd_apply_kernel<F32, true>), dim3(gx, p.nb), dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((norm_bwd_apply_kernel<F32, false>), dim3(gx, p.nb), dim3(256), lds, st, p);
+    }
     return check_launch("norm_bwd_apply");
 }
