@@ -324,24 +324,56 @@ __device__ __forceinline__ void c1_moments(const double* stats, int img, int npi
     rstd = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+// W = 4: four consecutive pixels per lane as one 16-byte access (npix a multiple of 4; they are exactly one
+// dropout group); W = 1: any npix.
+template <int W> struct PlanarVec;
+template <> struct PlanarVec<4> { using T = float4; };
+template <> struct PlanarVec<1> { using T = float; };
+template <int W>
+__device__ __forceinline__ void planar_load(const float* p, int g, float* v) {
+    const typename PlanarVec<W>::T t = reinterpret_cast<const typename PlanarVec<W>::T*>(p)[g];
+    if constexpr (W == 4) { v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; } else v[0] = t;
+}
+template <int W>
+__device__ __forceinline__ void planar_store(float* p, int g, const float* v) {
+    if constexpr (W == 4) reinterpret_cast<float4*>(p)[g] = make_float4(v[0], v[1], v[2], v[3]);
+    else p[g] = v[0];
+}
+template <bool DROP, int W>
+__device__ __forceinline__ void planar_keep(const DropKeys& dk, int g, bool* keep) {
+    if (DROP) {
+        if constexpr (W == 4) dropout_keep4(dk, (unsigned)g, keep);
+        else keep[0] = dropout_keep1(dk, (unsigned)g);
+    }
+}
+
+template <bool DROP, int W>
 __global__ __launch_bounds__(256) void norm1_fwd_kernel(const NormParams p) {
     const int img = blockIdx.y;
     float mean, rstd;
     c1_moments(p.stats, img, p.npix, p.eps, mean, rstd);
     const float alpha = *p.alpha;
     const DropKeys dk = dropout_keys(p.seed, p.layer, img, p.drop_thresh);
+    const float scale = p.drop_scale;
     const float* x = reinterpret_cast<const float*>(p.x) + (size_t)img * p.npix;
     float* out = reinterpret_cast<float*>(p.out) + (size_t)img * p.npix;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < p.npix; i += gridDim.x * 256) {
-        float d = (x[i] - mean) * rstd;
-        if (p.drop_thresh) {
-            const bool keep = dropout_keep1(dk, (unsigned)i);
-            d = keep ? d * p.drop_scale : 0.f;
+    const int ng = p.npix / W;
+    for (int g = blockIdx.x * 256 + threadIdx.x; g < ng; g += gridDim.x * 256) {
+        float v[W], o[W];
+        bool keep[W];
+        planar_load<W>(x, g, v);
+        planar_keep<DROP, W>(dk, g, keep);
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            float d = (v[j] - mean) * rstd;
+            if (DROP) d = keep[j] ? d * scale : 0.f;
+            o[j] = d > 0.f ? d : alpha * d;
         }
-        out[i] = d > 0.f ? d : alpha * d;
+        planar_store<W>(out, g, o);
     }
 }
 
+template <bool DROP, int W>
 __global__ __launch_bounds__(256) void norm1_bwd_reduce_kernel(const NormParams p) {
     __shared__ float red[3][4];
     const int img = blockIdx.y;
@@ -349,21 +381,27 @@ __global__ __launch_bounds__(256) void norm1_bwd_reduce_kernel(const NormParams 
     c1_moments(p.stats, img, p.npix, p.eps, mean, rstd);
     const float alpha = *p.alpha;
     const DropKeys dk = dropout_keys(p.seed, p.layer, img, p.drop_thresh);
+    const float scale = p.drop_scale;
     const float* x = reinterpret_cast<const float*>(p.x) + (size_t)img * p.npix;
     const float* dy = reinterpret_cast<const float*>(p.dy) + (size_t)img * p.npix;
     float s1 = 0.f, s2 = 0.f, da = 0.f;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < p.npix; i += gridDim.x * 256) {
-        const float xh = (x[i] - mean) * rstd;
-        float d = xh, sc = 1.f;
-        if (p.drop_thresh) {
-            const bool keep = dropout_keep1(dk, (unsigned)i);
-            sc = keep ? p.drop_scale : 0.f;
-            d = xh * sc;
+    const int ng = p.npix / W;
+    for (int g = blockIdx.x * 256 + threadIdx.x; g < ng; g += gridDim.x * 256) {
+        float v[W], gy[W];
+        bool keep[W];
+        planar_load<W>(x, g, v);
+        planar_load<W>(dy, g, gy);
+        planar_keep<DROP, W>(dk, g, keep);
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            const float xh = (v[j] - mean) * rstd;
+            float d = xh, sc = 1.f;
+            if (DROP) { sc = keep[j] ? scale : 0.f; d = xh * sc; }
+            float gh = gy[j] * (d > 0.f ? 1.f : alpha);
+            if (DROP) gh *= sc;
+            da += gy[j] * fminf(d, 0.f);
+            s1 += gh; s2 += gh * xh;
         }
-        const float g = dy[i];
-        const float gh = g * (d > 0.f ? 1.f : alpha) * sc;
-        da += g * fminf(d, 0.f);
-        s1 += gh; s2 += gh * xh;
     }
     s1 = wave_sum(s1); s2 = wave_sum(s2); da = wave_sum(da);
     const int w = threadIdx.x >> 6;
@@ -381,6 +419,7 @@ __global__ __launch_bounds__(256) void norm1_bwd_reduce_kernel(const NormParams 
     }
 }
 
+template <bool DROP, int W>
 __global__ __launch_bounds__(256) void norm1_bwd_apply_kernel(const NormParams p) {
     const int img = blockIdx.y;
     float mean, rstd;
@@ -394,19 +433,27 @@ __global__ __launch_bounds__(256) void norm1_bwd_apply_kernel(const NormParams p
     const float b1 = (float)(d1 / (double)p.npix), b2 = (float)(d2 / (double)p.npix);
     const float alpha = *p.alpha;
     const DropKeys dk = dropout_keys(p.seed, p.layer, img, p.drop_thresh);
+    const float scale = p.drop_scale;
     const float* x = reinterpret_cast<const float*>(p.x) + (size_t)img * p.npix;
     const float* dy = reinterpret_cast<const float*>(p.dy) + (size_t)img * p.npix;
     float* out = reinterpret_cast<float*>(p.out) + (size_t)img * p.npix;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < p.npix; i += gridDim.x * 256) {
-        const float xh = (x[i] - mean) * rstd;
-        float d = xh, sc = 1.f;
-        if (p.drop_thresh) {
-            const bool keep = dropout_keep1(dk, (unsigned)i);
-            sc = keep ? p.drop_scale : 0.f;
-            d = xh * sc;
+    const int ng = p.npix / W;
+    for (int g = blockIdx.x * 256 + threadIdx.x; g < ng; g += gridDim.x * 256) {
+        float v[W], gy[W], o[W];
+        bool keep[W];
+        planar_load<W>(x, g, v);
+        planar_load<W>(dy, g, gy);
+        planar_keep<DROP, W>(dk, g, keep);
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            const float xh = (v[j] - mean) * rstd;
+            float d = xh, sc = 1.f;
+            if (DROP) { sc = keep[j] ? scale : 0.f; d = xh * sc; }
+            float gh = gy[j] * (d > 0.f ? 1.f : alpha);
+            if (DROP) gh *= sc;
+            o[j] = rstd * (gh - b1 - xh * b2);
         }
-        const float gh = dy[i] * (d > 0.f ? 1.f : alpha) * sc;
-        out[i] = rstd * (gh - b1 - xh * b2);
+        planar_store<W>(out, g, o);
     }
 }
 
@@ -442,6 +489,19 @@ int norm_bwd_reduce_blocks(int npix, int c) {
     return g > gmin ? g : gmin;
 }
 
+// planar kernels: 16-byte accesses when every image starts on a 16-byte boundary
+static bool planar_v4(const NormParams& p) {
+    auto al = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    return p.npix % 4 == 0 && al(p.x) && al(p.out) && (!p.dy || al(p.dy));
+}
+#define NORM1_CASE(K, GRID)                                                                      \
+    do {                                                                                         \
+        if (p.drop_thresh) { if (v4) hipLaunchKernelGGL((K<true, 4>), GRID, dim3(256), 0, st, p); \
+                             else hipLaunchKernelGGL((K<true, 1>), GRID, dim3(256), 0, st, p); }  \
+        else { if (v4) hipLaunchKernelGGL((K<false, 4>), GRID, dim3(256), 0, st, p);              \
+               else hipLaunchKernelGGL((K<false, 1>), GRID, dim3(256), 0, st, p); }               \
+    } while (0)
+
 // dtype: 0 fp32, 1 bf16.  c == 1 selects the planar fp32 kernels (pitch must be 1, dtype 0).
 int launch_norm_fwd(int dtype, const NormParams& p, hipStream_t st) {
     {
@@ -451,8 +511,9 @@ int launch_norm_fwd(int dtype, const NormParams& p, hipStream_t st) {
     MI_CHECK(!p.drop_thresh || (long long)p.npix * p.c < (1ll << 34), "dropout numbers the elements of one image in 34 bits");
     if (p.c == 1) {
         MI_CHECK(dtype == 0 && p.x_pitch == 1 && p.out_pitch == 1 && !p.res, "one-channel tensors are planar fp32");
-        int gx = (p.npix + 1023) / 1024; if (gx > 256) gx = 256;
-        hipLaunchKernelGGL(norm1_fwd_kernel, dim3(gx, p.nb), dim3(256), 0, st, p);
+        const bool v4 = planar_v4(p);
+        int gx = (p.npix / (v4 ? 4 : 1) + 511) / 512; if (gx > 256) gx = 256; if (gx < 1) gx = 1;
+        NORM1_CASE(norm1_fwd_kernel, dim3(gx, p.nb));
         return check_launch("norm1_fwd");
     }
     const int vec = dtype ? 8 : 4;
@@ -484,11 +545,12 @@ int launch_norm_bwd(int dtype, const NormParams& p, hipStream_t st) {
     MI_CHECK(!p.drop_thresh || (long long)p.npix * p.c < (1ll << 34), "dropout numbers the elements of one image in 34 bits");
     if (p.c == 1) {
         MI_CHECK(dtype == 0 && p.x_pitch == 1 && p.out_pitch == 1 && p.dy_pitch == 1, "one-channel tensors are planar fp32");
+        const bool v4 = planar_v4(p);
         const int gx = norm_bwd_reduce_blocks(p.npix, 1);
-        hipLaunchKernelGGL(norm1_bwd_reduce_kernel, dim3(gx, p.nb), dim3(256), 0, st, p);
+        NORM1_CASE(norm1_bwd_reduce_kernel, dim3(gx, p.nb));
         if (int r = check_launch("norm1_bwd_reduce")) return r;
-        int ga = (p.npix + 1023) / 1024; if (ga > 256) ga = 256;
-        hipLaunchKernelGGL(norm1_bwd_apply_kernel, dim3(ga, p.nb), dim3(256), 0, st, p);
+        int ga = (p.npix / (v4 ? 4 : 1) + 511) / 512; if (ga > 256) ga = 256; if (ga < 1) ga = 1;
+        NORM1_CASE(norm1_bwd_apply_kernel, dim3(ga, p.nb));
         return check_launch("norm1_bwd_apply");
     }
     const int vec = dtype ? 8 : 4;
