@@ -439,6 +439,60 @@ __global__ __launch_bounds__(256) void stencil_kernel(const StencilParams p) {
     *reinterpret_cast<float4*>(p.out + o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
 }
 
+// 2-D variant: a thread owns four consecutive pixels of ST_R consecutive rows.  All ST_R + 2 input rows are
+// requested before the first use (one 16-byte load plus the two neighbours per row), so each input row is
+// fetched (ST_R + 2) / ST_R times instead of three times and a thread has its whole working set in flight.
+constexpr int ST_R = 8;
+__global__ __launch_bounds__(256) void stencil2d_strip_kernel(const StencilParams p) {
+    const int H = p.d[1], W = p.d[2];
+    const int qrow = W >> 2;
+    const int nstrip = (H + ST_R - 1) / ST_R;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= qrow * nstrip) return;
+    const int strip = t / qrow;
+    const int x0 = (t - strip * qrow) * 4, y0 = strip * ST_R;
+    const size_t ibase = (size_t)blockIdx.y * H * W;
+    const float* in = p.in + ibase;
+    float w[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) w[k] = p.w[p.flip ? 8 - k : k];
+    const float b = p.bias ? p.bias[0] : 0.f;
+    float v[ST_R + 2][6];
+#pragma unroll
+    for (int r = 0; r < ST_R + 2; ++r) {
+        const int yy = y0 - 1 + r;
+        if ((unsigned)yy < (unsigned)H) {
+            const float* row = in + (size_t)yy * W;
+            const float4 c = *reinterpret_cast<const float4*>(row + x0);
+            v[r][0] = x0 > 0 ? row[x0 - 1] : 0.f;
+            v[r][1] = c.x; v[r][2] = c.y; v[r][3] = c.z; v[r][4] = c.w;
+            v[r][5] = x0 + 4 < W ? row[x0 + 4] : 0.f;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) v[r][j] = 0.f;
+        }
+    }
+    float4 add[ST_R];
+    if (p.addend) {
+#pragma unroll
+        for (int r = 0; r < ST_R; ++r)
+            if (y0 + r < H) add[r] = *reinterpret_cast<const float4*>(p.addend + ibase + (size_t)(y0 + r) * W + x0);
+    }
+#pragma unroll
+    for (int r = 0; r < ST_R; ++r) {
+        if (y0 + r >= H) break;
+        float acc[4] = {b, b, b, b};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] += w[ky * 3 + kx] * v[r + ky][j + kx];
+        if (p.addend) { acc[0] += add[r].x; acc[1] += add[r].y; acc[2] += add[r].z; acc[3] += add[r].w; }
+        *reinterpret_cast<float4*>(p.out + ibase + (size_t)(y0 + r) * W + x0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
+
 // any row length: one pixel per thread
 __global__ __launch_bounds__(256) void stencil_scalar_kernel(const StencilParams p) {
     const int KZ = p.ndim == 3 ? 3 : 1;
@@ -625,7 +679,10 @@ int launch_stencil(const StencilParams& p, hipStream_t st) {
     if (p.d[2] % 4 == 0) {
         const unsigned gx = (unsigned)((npix / 4 + 255) / 256);
         if (p.ndim == 3) hipLaunchKernelGGL(stencil_kernel<3>, dim3(gx, p.nb), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL(stencil_kernel<1>, dim3(gx, p.nb), dim3(256), 0, st, p);
+        else if (p.d[1] >= 4 * ST_R) {
+            const int threads = (p.d[2] >> 2) * ((p.d[1] + ST_R - 1) / ST_R);
+            hipLaunchKernelGGL(stencil2d_strip_kernel, dim3((threads + 255) / 256, p.nb), dim3(256), 0, st, p);
+        } else hipLaunchKernelGGL(stencil_kernel<1>, dim3(gx, p.nb), dim3(256), 0, st, p);
     } else {
         hipLaunchKernelGGL(stencil_scalar_kernel, dim3((unsigned)((npix + 255) / 256), p.nb), dim3(256), 0, st, p);
     }
