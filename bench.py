@@ -115,7 +115,8 @@ def main():
     ap.add_argument("--mode", default="train", choices=("train", "infer", "pipeline"),
                     help="infer: sliding-window evaluation of --batch slices per GPU and step (roi 256, 9 windows per slice)")
     ap.add_argument("--roi", type=int, default=256)
-    ap.add_argument("--sw-batch", type=int, default=36, help="windows per model call in --mode infer")
+    ap.add_argument("--sw-batch", type=int, default=288,
+                    help="windows per model call in --mode infer (reference/train.py:140 passes 4; windows are independent samples, so the count changes throughput only)")
     args = ap.parse_args()
 
     import unet_amd

@@ -52,3 +52,26 @@ def test_per_volume_dice_matches_oracle(dev):
     table2, mean2 = VolumeEvaluator(m, (32, 32), sw_batch_size=16, slices_per_call=7).evaluate(x.to(dev), t.to(dev), names)
     assert abs(mean2 - mean) < 1e-6 and all(abs(table2[k] - table[k]) < 1e-6 for k in table)
     assert m.training is False
+
+
+def test_window_grouping_keeps_results_and_respects_other_predictors(dev, monkeypatch):
+    """The package's U-Net in eval mode may be fed more windows per call than sw_batch_size (they are independent
+    samples); any other predictor gets exactly the group size it was asked for."""
+    torch.manual_seed(4)
+    m = unet_amd.UNet(2, 1, 1, (16, 32, 64), (2, 2), num_res_units=2, compute_dtype=torch.float32).to(dev).eval()
+    x = torch.rand(3, 1, 80, 80, generator=torch.Generator().manual_seed(6)).to(dev)
+    grouped = unet_amd.sliding_window_inference(x, (32, 32), 4, m)
+    monkeypatch.setenv("UNET_AMD_SW_EXACT", "1")
+    exact = unet_amd.sliding_window_inference(x, (32, 32), 4, m)
+    monkeypatch.delenv("UNET_AMD_SW_EXACT")
+    assert float((grouped - exact).abs().max()) < 1e-5 * float(exact.abs().max())
+    sizes = []
+    unet_amd.sliding_window_inference(x, (32, 32), 4, lambda w: (sizes.append(w.shape[0]), w)[1])
+    nwin = len(unet_amd.window_starts([80, 80], [32, 32], 0.25)) * 3
+    assert max(sizes) == 4 and sum(sizes) == nwin
+    m.train()
+    sizes.clear()
+    from unet_amd.inferers import _windows_per_call
+    assert _windows_per_call(m, 4, nwin, 32 * 32) == 4           # dropout masks depend on the position in the batch
+    m.eval()
+    assert _windows_per_call(m, 4, nwin, 32 * 32) == min(nwin, 288)

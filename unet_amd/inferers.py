@@ -52,6 +52,25 @@ def shard_range(n_items: int, rank: int, world: int):
     return lo, min(n_items, lo + per)
 
 
+SW_GROUP_WINDOWS = 288   # windows per model call when the predictor is known to treat samples independently
+
+
+def _windows_per_call(predictor, sw_batch_size: int, total: int, window_elems: int) -> int:
+    """MONAI's ``sw_batch_size`` only bounds memory.  For this package's U-Net in eval mode every window is an
+    independent sample (instance norm, dropout off), so a larger group gives the same numbers in fewer, fuller
+    launches; any other predictor gets exactly the group size it was asked for (``UNET_AMD_SW_EXACT=1`` forces
+    that for the U-Net too)."""
+    import os
+
+    from .nets import UNet
+
+    n = max(1, int(sw_batch_size))
+    if isinstance(predictor, UNet) and not predictor.training and os.environ.get("UNET_AMD_SW_EXACT", "0") != "1":
+        cap = max(1, (1 << 28) // max(1, window_elems))       # keep one group's input below 1 GiB of fp32
+        n = max(n, min(total, SW_GROUP_WINDOWS, cap))
+    return n
+
+
 def sliding_window_inference(inputs: torch.Tensor, roi_size, sw_batch_size: int,
                              predictor: Callable[[torch.Tensor], torch.Tensor], overlap: float = 0.25,
                              mode: str = "constant", sigma_scale=0.125, padding_mode: str = "constant",
@@ -90,8 +109,9 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size, sw_batch_size: int,
         rpix *= r
     win_out = torch.empty((total, 1) + tuple(roi), dtype=torch.float32, device=dev)
     stream = _lib.current_stream(dev)
-    for g in range(0, total, sw_batch_size):
-        n = min(sw_batch_size, total - g)
+    group = _windows_per_call(predictor, sw_batch_size, total, rpix)
+    for g in range(0, total, group):
+        n = min(group, total - g)
         wins = torch.empty((n, 1) + tuple(roi), dtype=torch.float32, device=dev)
         _lib.check(lib.mi_sw_gather(x.data_ptr(), wins.data_ptr(), starts_dev.data_ptr(), nwin, g, n, nb, img3, roi3,
                                     pad3, float(cval), stream), "mi_sw_gather")
