@@ -14,6 +14,9 @@ def label(name: str) -> str:
     m = re.search(r"(\w+)<(BF16|F32)((?:, [\w-]+)*)>", name)
     base = re.sub(r"^void |\(anonymous namespace\)::", "", name).split("(")[0]
     if not m:
+        base = re.sub(r"<.*$", "", base)
+        if base in ("norm1_bwd_reduce_kernel", "norm1_bwd_apply_kernel"):
+            return "norm1_bwd_kernels"
         return base
     kern, tr, rest = m.group(1), m.group(2), [a.strip() for a in m.group(3).split(",") if a.strip()]
     if kern in ("norm_bwd_reduce_kernel", "norm_bwd_apply_kernel"):
@@ -33,15 +36,28 @@ def load(path):
     return d
 
 
+def by_kernel(path, counter, dst):
+    """per-kernel-symbol sums of one counter pass, as committed under profiles/"""
+    d = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        d[r["Kernel_Name"]][0] += 1; d[r["Kernel_Name"]][1] += float(r["Counter_Value"])
+    with open(dst, "w") as f:
+        f.write(f"Kernel_Name,Dispatches,{counter}_sum_KiB\n")
+        for k, (n, v) in sorted(d.items(), key=lambda kv: -kv[1][1]):
+            f.write('"%s",%d,%.1f\n' % (k, n, v))
+
+
 def main():
     fetch, write, tag = load(sys.argv[1]), load(sys.argv[2]), sys.argv[3]
+    by_kernel(sys.argv[1], "FETCH_SIZE", f"profiles/{tag}_pmc_fetch_size_by_kernel.csv")
+    by_kernel(sys.argv[2], "WRITE_SIZE", f"profiles/{tag}_pmc_write_size_by_kernel.csv")
     out = {}
     for k in sorted(set(fetch) | set(write)):
         f, nf = fetch.get(k, [0.0, 0]); w, nw = write.get(k, [0.0, 0])
         n = max(nf, nw)
         if n == 0 or k.startswith("at::") or "Cijk" in k:
             continue
-        pair = 2 if k.startswith("norm_bwd_kernels") else 1      # two kernels make one bench step
+        pair = 2 if k.startswith(("norm_bwd_kernels", "norm1_bwd_kernels")) else 1      # two kernels make one bench step
         launches = n / pair
         out[k] = {"bytes_per_launch": round((2.0 * f + w) * 1024.0 / launches), "read_bytes_per_launch": round(2.0 * f * 1024.0 / launches),
                   "write_bytes_per_launch": round(w * 1024.0 / launches), "launches_profiled": launches}

@@ -1,0 +1,27 @@
+#!/bin/bash
+# GPU-side collection for profiles/: usage scripts/profile_collect.sh STAGE   (outputs under gpurun_out/prof/)
+#   pmc   : FETCH_SIZE and WRITE_SIZE passes (one counter per pass)
+#   trace : kernel traces (single stream and production schedule) and bench.py's own tables
+set -o pipefail
+STAGE=${1:-trace}
+OUT=gpurun_out/prof
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+if [ "$STAGE" = pmc ]; then
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf $OUT/pmc_$c
+    timeout -s KILL 200 rocprofv3 --pmc $c -d $OUT/pmc_$c -o pmc --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $OUT/pmc_$c.log 2>&1 || exit 1
+    cp "$(find $OUT/pmc_$c -name '*counter_collection.csv' | head -1)" $OUT/pmc_$c.csv || exit 1
+    rm -rf $OUT/pmc_$c
+  done
+  ls -la $OUT
+else
+  rm -rf $OUT/t1 $OUT/t2
+  MI_NO_SIDE_STREAM=1 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $OUT/t1 -o r --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing > $OUT/trace1.log 2>&1 || exit 1
+  cp "$(find $OUT/t1 -name '*kernel_stats.csv' | head -1)" $OUT/kernel_stats.csv || exit 1
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $OUT/t2 -o r --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing > $OUT/trace2.log 2>&1 || exit 1
+  cp "$(find $OUT/t2 -name '*kernel_stats.csv' | head -1)" $OUT/kernel_stats_overlapped.csv || exit 1
+  rm -rf $OUT/t1 $OUT/t2
+  BENCH_LAYERS=1 timeout -k 10 300 python bench.py > $OUT/bench.json 2> $OUT/per_layer.txt || exit 1
+  cat $OUT/bench.json
+fi
