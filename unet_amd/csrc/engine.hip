@@ -44,7 +44,7 @@ struct Reloc { size_t field_off; int base; };
 
 struct AddArgs { char* dst; int dpitch, dcoff; const char* src; int spitch, scoff, c; long long npix; };
 struct MemsetArgs { char* ptr; size_t bytes; };
-struct TabArgs { int first, count, max_elems; };
+struct TabArgs { int first, count, max_elems; };   // max_elems: packs: largest element count; reductions: workgroups of the launch
 
 struct Step {
     int kind = 0, dtype = 0, bucket = 0;
@@ -179,7 +179,7 @@ struct Builder {
         int hasb = 0;
         if (!bname.empty()) { d.dst_b = (float*)(uintptr_t)(poff(bname) * sizeof(float)); hasb = 1; }
         u.reduces.push_back(d); u.reduce_has_b.push_back(hasb);
-        bucket_of_reduce.push_back(cur_bucket);
+        group_of_reduce.push_back(n_reduce_steps);
     }
     // scalar copy (PReLU slope gradient) or zero fill (nslab = 0)
     void add_scalar_reduce(size_t src_off, int nslab, const std::string& name, int count = 1) {
@@ -188,9 +188,15 @@ struct Builder {
         d.nslab = nslab; d.ntaps = 1; d.Ftot = count; d.S = 1; d.f_off = 0; d.Fcnt = count; d.KK = 1; d.kidx[0] = 0;
         d.dst_w = (float*)(uintptr_t)(poff(name) * sizeof(float));
         u.reduces.push_back(d); u.reduce_has_b.push_back(0);
-        bucket_of_reduce.push_back(cur_bucket);
+        group_of_reduce.push_back(n_reduce_steps);
     }
-    std::vector<int> bucket_of_reduce;
+    // a reduction descriptor belongs to the next K_REDUCE step pushed after it
+    std::vector<int> group_of_reduce;
+    int n_reduce_steps = 0;
+    void push_reduce_step(const std::string& layer) {
+        Step& s = push(u.bwd, K_REDUCE, layer); s.kernel = "reduce_kernel";
+        ++n_reduce_steps;
+    }
 
     // ---- steps ---------------------------------------------------------------------------------
     Step& push(std::vector<Step>& list, int kind, const std::string& layer) {
@@ -744,7 +750,7 @@ bool build(mi_unet& u) {
             B.add_reduce(po, pb, nslab, nt, K, outc, 0, K, KK, nat, P + ".0.conv.weight", "");
             B.add_scalar_reduce(0, 0, P + ".0.conv.bias", outc);
         }
-        { Step& s = B.push(u.bwd, K_REDUCE, "reduce gradients: decoder bucket"); s.kernel = "reduce_kernel"; }
+        B.push_reduce_step("reduce gradients: decoder bucket");
         // ---- bottom ----
         B.cur_bucket = 1;
         {
@@ -802,7 +808,7 @@ bool build(mi_unet& u) {
                 s.work = (double)nb * u.rp[res] * cin * esz * 3.0;
             }
         }
-        { Step& s = B.push(u.bwd, K_REDUCE, "reduce gradients: bottom bucket"); s.kernel = "reduce_kernel"; }
+        B.push_reduce_step("reduce gradients: bottom bucket");
         // ---- down path ----
         B.cur_bucket = 2;
         for (int l = L - 2; l >= 0; --l) {
@@ -867,32 +873,33 @@ bool build(mi_unet& u) {
                 }
             }
         }
-        { Step& s = B.push(u.bwd, K_REDUCE, "reduce gradients: encoder bucket"); s.kernel = "reduce_kernel"; }
+        B.push_reduce_step("reduce gradients: encoder bucket");
     }
 
     // ---- descriptor tables ----
     // reorder packs so that the forward packs come first (they already do: backward packs were appended later)
     u.off_pack_tab = B.alloc(u.packs.size() * sizeof(PackDesc) + 256);
     u.off_reduce_tab = B.alloc(u.reduces.size() * sizeof(ReduceDesc) + 256);
-    // reduces are grouped by bucket in creation order; find ranges
+    // reduces are grouped by their K_REDUCE step in creation order; find ranges
     {
-        int first[3] = {-1, -1, -1}, cnt[3] = {0, 0, 0};
-        for (size_t i = 0; i < B.bucket_of_reduce.size(); ++i) {
-            const int b = B.bucket_of_reduce[i];
-            if (first[b] < 0) first[b] = (int)i;
-            cnt[b]++;
+        std::vector<int> first(B.n_reduce_steps, -1), cnt(B.n_reduce_steps, 0);
+        for (size_t i = 0; i < B.group_of_reduce.size(); ++i) {
+            const int g = B.group_of_reduce[i];
+            if (g >= B.n_reduce_steps) { mi_set_error("gradient reduction without a launch"); return false; }
+            if (first[g] < 0) first[g] = (int)i;
+            cnt[g]++;
         }
         int k = 0;
         for (Step& s : u.bwd)
             if (s.kind == K_REDUCE) {
                 s.tab.first = first[k] < 0 ? 0 : first[k]; s.tab.count = cnt[k];
-                int mx = 1;
+                int blk = 0;
                 for (int i = s.tab.first; i < s.tab.first + s.tab.count; ++i) {
-                    const ReduceDesc& d = u.reduces[i];
-                    const int e = d.ntaps * d.Fcnt * d.S + d.Fcnt;
-                    if (e > mx) mx = e;
+                    ReduceDesc& d = u.reduces[i];
+                    d.blk0 = blk; d.nblk = reduce_blocks_for(d.ntaps * d.Fcnt * d.S + d.Fcnt);
+                    blk += d.nblk;
                 }
-                s.tab.max_elems = mx;
+                s.tab.max_elems = blk;
                 ++k;
             }
     }

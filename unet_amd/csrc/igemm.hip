@@ -936,11 +936,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 // ---------------------------------------------------------------------------------
 // slab reduction and weight packing (descriptor tables in device memory)
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ void reduce_body(const ReduceDesc& d);
+__device__ __forceinline__ void reduce_body(const ReduceDesc& d, int blk, int nblk);
 template <class TR>
 __device__ __forceinline__ void pack_body(const PackDesc& d);
-__global__ __launch_bounds__(256) void reduce_kernel(const ReduceDesc* __restrict__ descs) {
-    reduce_body(descs[blockIdx.y]);
+// one launch for a table of descriptors: workgroup b serves the descriptor whose range [blk0, blk0 + nblk) holds b
+__global__ __launch_bounds__(256) void reduce_kernel(const ReduceDesc* __restrict__ descs, int ndesc) {
+    int i = 0;
+    while (i + 1 < ndesc && (int)blockIdx.x >= descs[i + 1].blk0) ++i;
+    reduce_body(descs[i], (int)blockIdx.x - descs[i].blk0, descs[i].nblk);
 }
 template <class TR>
 __global__ __launch_bounds__(256) void pack_kernel(const PackDesc* __restrict__ descs) {
@@ -951,7 +954,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackDesc* __restrict__ 
 // 256 threads = EL output elements x SG slab groups (EL = 64, 16, 4 or 1: few outputs with many slabs get more
 // slab groups).  Each thread sums its slabs in slab order with eight loads in flight, the group sums are
 // combined by a fixed-shape tree through LDS, so the result is bitwise reproducible.
-__device__ __forceinline__ void reduce_body(const ReduceDesc& d) {
+__device__ __forceinline__ void reduce_body(const ReduceDesc& d, int blk, int nblk) {
     __shared__ float part[256];
     const int nw = d.ntaps * d.Fcnt * d.S;
     const int total = nw + (d.dst_b ? d.Fcnt : 0);
@@ -960,7 +963,7 @@ __device__ __forceinline__ void reduce_body(const ReduceDesc& d) {
     const int lx = threadIdx.x % EL, ly = threadIdx.x / EL;
     const int nslab = d.nslab;
     const size_t stride = (size_t)d.ntaps * d.Ftot * d.S;
-    for (int base = blockIdx.x * EL; base < total; base += gridDim.x * EL) {
+    for (int base = blk * EL; base < total; base += nblk * EL) {
         const int i = base + lx;
         float a = 0.f;
         int s = 0, f = 0, t = 0;
@@ -1001,7 +1004,7 @@ __device__ __forceinline__ void reduce_body(const ReduceDesc& d) {
         __syncthreads();
     }
 }
-__global__ __launch_bounds__(256) void reduce_one_kernel(const ReduceDesc d) { reduce_body(d); }
+__global__ __launch_bounds__(256) void reduce_one_kernel(const ReduceDesc d) { reduce_body(d, blockIdx.x, gridDim.x); }
 
 template <class TR>
 __device__ __forceinline__ void pack_body(const PackDesc& d) {
@@ -1288,12 +1291,18 @@ int launch_ksplit_finish(int dtype, const IgemmParams& pin, hipStream_t st) {
     return 0;
 }
 
-int launch_reduce(const ReduceDesc* d_descs, int ndesc, int max_elems, hipStream_t st) {
-    if (ndesc <= 0) return 0;
-    int gx = (max_elems + 63) / 64;
-    if (gx > 2048) gx = 2048;
-    if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(reduce_kernel, dim3(gx, ndesc), dim3(256), 0, st, d_descs);
+// workgroups a descriptor with `total` output elements keeps busy: reduce_body gives a workgroup 64, 16, 4 or 1
+// of them (few outputs with many slabs get more slab groups instead)
+int reduce_blocks_for(int total) {
+    const int el = total >= 2048 ? 64 : total >= 256 ? 16 : total >= 16 ? 4 : 1;
+    int g = (total + el - 1) / el;
+    return g > 2048 ? 2048 : g < 1 ? 1 : g;
+}
+
+// total_blocks: sum of the descriptors' nblk (each set from reduce_blocks_for(), blk0 = running sum)
+int launch_reduce(const ReduceDesc* d_descs, int ndesc, int total_blocks, hipStream_t st) {
+    if (ndesc <= 0 || total_blocks <= 0) return 0;
+    hipLaunchKernelGGL(reduce_kernel, dim3(total_blocks), dim3(256), 0, st, d_descs, ndesc);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { mi_set_error(std::string("reduce launch: ") + hipGetErrorString(e)); return -2; }
     return 0;
@@ -1312,8 +1321,7 @@ int launch_pack(int dtype, const PackDesc* d_descs, int ndesc, int max_elems, hi
 }
 
 int launch_reduce_one(const ReduceDesc& d, hipStream_t st) {
-    int total = d.ntaps * d.Fcnt * d.S + d.Fcnt;
-    int gx = (total + 63) / 64; if (gx > 2048) gx = 2048; if (gx < 1) gx = 1;
+    const int gx = reduce_blocks_for(d.ntaps * d.Fcnt * d.S + d.Fcnt);
     hipLaunchKernelGGL(reduce_one_kernel, dim3(gx), dim3(256), 0, st, d);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { mi_set_error(std::string("reduce launch: ") + hipGetErrorString(e)); return -2; }

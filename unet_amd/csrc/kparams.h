@@ -66,6 +66,7 @@ struct ReduceDesc {
     int nslab, ntaps, Ftot, S, f_off, Fcnt, KK;
     int kidx[MI_MAX_TAPS];
     float* dst_w; float* dst_b;             // dst_b may be null
+    int blk0, nblk;                         // table launches: this descriptor owns workgroups [blk0, blk0 + nblk) of its launch
 };
 
 // Weight packing: dst[((t*Ntot + n_off + n)*Ktot + k_off + k)] = src[n*sn + k*sk + kidx[t]]
@@ -134,7 +135,8 @@ struct StencilParams {
 extern "C++" {
 int launch_igemm(int dtype, const IgemmParams& p, hipStream_t st);
 int launch_wgrad(int dtype, const WgradParams& p, hipStream_t st);
-int launch_reduce(const ReduceDesc* d_descs, int ndesc, int max_elems, hipStream_t st);
+int launch_reduce(const ReduceDesc* d_descs, int ndesc, int total_blocks, hipStream_t st);
+int reduce_blocks_for(int total);
 int launch_pack(int dtype, const PackDesc* d_descs, int ndesc, int max_elems, hipStream_t st);
 int launch_reduce_one(const ReduceDesc& d, hipStream_t st);
 int c1_wgrad_slabs(int N, const int cd[3]);
