@@ -8,6 +8,7 @@
 namespace {
 
 constexpr int C1_WGRAD_CG = 8;   // channels per thread of c1_s2_wgrad_kernel
+constexpr int C1W_RU = 4;        // rows in flight per thread of c1_s2_wgrad_kernel
 constexpr int C1F_YG = 1;        // groups of four coarse rows per workgroup of c1_s2_fwd_kernel
 constexpr int C1T_YP = 4;        // patches along y per workgroup of c1_s2_T_kernel
 
@@ -283,7 +284,14 @@ __global__ __launch_bounds__(256) void c1_s2_T_kernel(const C1Params p) {
 //      partial_bias[slab][n] = sum_c Y[c][n].  blockIdx.y = kz plane in 3-D.
 // Thread = (coarse column, group of 8 channels); blockIdx.x = (column block, row block), the row block strides
 // over all (image, z, y) rows so that no per-lane division is needed.  Channels >= n_y1 come from y2.
-template <class TR>
+// QUAD (N = 32: the four channel groups of a pixel are the four lanes of a quad): lane ky of the quad loads the three
+// image values of stencil row ky and the quad exchanges them with DPP broadcasts, so a thread issues 3 instead
+// of 9 scattered 4-byte loads per row: these loads, not the bytes, bound the kernel.
+template <int K>
+__device__ __forceinline__ float quad_bcast(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), K * 0x55, 0xf, 0xf, false));
+}
+template <class TR, bool QUAD>
 __global__ __launch_bounds__(256) void c1_s2_wgrad_kernel(const C1Params p) {
     constexpr int ESZ = TR::ESZ;
     constexpr int CG = C1_WGRAD_CG;   // channels per thread: few registers, many waves per SIMD
@@ -314,33 +322,74 @@ __global__ __launch_bounds__(256) void c1_s2_wgrad_kernel(const C1Params p) {
     const int ypitch = second ? p.y2_pitch : p.y_pitch;
     const int ych = second ? p.y2_coff + grp * CG - p.n_y1 : p.y_coff + grp * CG;
     const int nrows = p.nb * p.cd[0] * p.cd[1];
-    if (rb < nrb)   // workgroups beyond the last full row block (grid not a multiple of xblocks) only write zeros
-    for (int row = rb; row < nrows; row += nrb) {
-        const int cy = row % p.cd[1]; const int r2 = row / p.cd[1];
-        const int cz = r2 % p.cd[0]; const int img = r2 / p.cd[0];
-        if (!lane_ok) continue;
-        float v[CG];
-        load_n<TR, CG>(ysrc + (((size_t)row * p.cd[2] + cx) * ypitch + ych) * ESZ, v);
+    // A workgroup walks its rows C1W_RU at a time: all loads of a step (one channel vector and nine image values
+    // per row) are issued before the first use, so a thread has C1W_RU rows in flight instead of one and the
+    // walk takes a quarter of the dependent round trips.
+    constexpr int RV = CG * ESZ / 16;          // 16-byte vectors per channel group
+    if (rb < nrb && lane_ok)   // workgroups beyond the last full row block (grid not a multiple of xblocks) only write zeros
+    for (int row0 = rb; row0 < nrows; row0 += nrb * C1W_RU) {
+        uint4 yr[C1W_RU][RV];
+        float xv[C1W_RU][QUAD ? 3 : 9];
+        bool rowok[C1W_RU], zok[C1W_RU];
 #pragma unroll
-        for (int e = 0; e < CG; ++e) accb[e] += v[e];
-        const int fz = (p.ndim == 3) ? 2 * cz - 1 + kz : 0;
-        if ((unsigned)fz >= (unsigned)p.fd[0]) continue;
-        const float* xin = p.x1 + (size_t)img * fpix + (size_t)fz * p.fd[1] * p.fd[2];
-        float xv[9];
+        for (int u = 0; u < C1W_RU; ++u) {
+            const int row = row0 + u * nrb;
+            rowok[u] = row < nrows; zok[u] = false;
+            if (!rowok[u]) continue;
+            const int cy = row % p.cd[1]; const int r2 = row / p.cd[1];
+            const int cz = r2 % p.cd[0]; const int img = r2 / p.cd[0];
+            const char* ysrc_p = ysrc + (((size_t)row * p.cd[2] + cx) * ypitch + ych) * ESZ;
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int fy = 2 * cy - 1 + ky;
-            const bool rok = (unsigned)fy < (unsigned)p.fd[1];
+            for (int q = 0; q < RV; ++q) yr[u][q] = *reinterpret_cast<const uint4*>(ysrc_p + q * 16);
+            const int fz = (p.ndim == 3) ? 2 * cz - 1 + kz : 0;
+            zok[u] = (unsigned)fz < (unsigned)p.fd[0];
+            if (!zok[u]) continue;
+            const float* xin = p.x1 + (size_t)img * fpix + (size_t)fz * p.fd[1] * p.fd[2];
+            if (QUAD) {
+                const int fy = 2 * cy - 1 + grp;
+                const bool rok = grp < 3 && (unsigned)fy < (unsigned)p.fd[1];
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int fx = 2 * cx - 1 + kx;
-                xv[ky * 3 + kx] = (rok && (unsigned)fx < (unsigned)p.fd[2]) ? xin[(size_t)fy * p.fd[2] + fx] : 0.f;
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int fx = 2 * cx - 1 + kx;
+                    xv[u][kx] = (rok && (unsigned)fx < (unsigned)p.fd[2]) ? xin[(size_t)fy * p.fd[2] + fx] : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int fy = 2 * cy - 1 + ky;
+                    const bool rok = (unsigned)fy < (unsigned)p.fd[1];
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int fx = 2 * cx - 1 + kx;
+                        xv[u][ky * 3 + kx] = (rok && (unsigned)fx < (unsigned)p.fd[2]) ? xin[(size_t)fy * p.fd[2] + fx] : 0.f;
+                    }
+                }
             }
         }
 #pragma unroll
-        for (int k = 0; k < 9; ++k)
+        for (int u = 0; u < C1W_RU; ++u) {
+            if (!rowok[u]) continue;
+            float v[CG];
 #pragma unroll
-            for (int e = 0; e < CG; ++e) acc[e][k] += v[e] * xv[k];
+            for (int q = 0; q < RV; ++q) unpack_vec<TR>(yr[u][q], v + q * TR::VEC);
+#pragma unroll
+            for (int e = 0; e < CG; ++e) accb[e] += v[e];
+            if (!zok[u]) continue;
+            float x9[9];
+            if (QUAD) {
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    x9[kx] = quad_bcast<0>(xv[u][kx]); x9[3 + kx] = quad_bcast<1>(xv[u][kx]); x9[6 + kx] = quad_bcast<2>(xv[u][kx]);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) x9[k] = xv[u][k];
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+#pragma unroll
+                for (int e = 0; e < CG; ++e) acc[e][k] += v[e] * x9[k];
+        }
     }
     (void)cpix;
     // lanes that share a channel group: xor-reduce over lane bits >= log2(G) when G divides the wave
@@ -655,7 +704,7 @@ int launch_c1_s2_T(int dtype, const C1Params& p, hipStream_t st) {
 int c1_wgrad_slabs(int N, const int cd[3]) {
     const int ppb = 256 / (N / C1_WGRAD_CG);
     const int xblocks = (cd[2] + ppb - 1) / ppb;
-    int rb = 1024 / xblocks;
+    int rb = 768 / xblocks;         // three workgroups per CU fit the register file: all resident at once
     if (rb < 1) rb = 1;
     return xblocks * rb;
 }
@@ -666,11 +715,16 @@ int launch_c1_s2_wgrad(int dtype, const C1Params& p, hipStream_t st) {
     MI_CHECK(p.n_y1 % 8 == 0 && p.n_y1 > 0 && (p.n_y1 >= p.N || p.y2 != nullptr), "second source missing or misaligned");
     MI_CHECK(p.nsplit == c1_wgrad_slabs(p.N, p.cd), "nsplit must come from c1_wgrad_slabs()");
     const size_t lds = (size_t)4 * p.N * 10 * sizeof(float);
-    if (dtype) { if (int rc = small_lds(c1_s2_wgrad_kernel<BF16>, lds)) return rc; }
-    else { if (int rc = small_lds(c1_s2_wgrad_kernel<F32>, lds)) return rc; }
+    const bool quad = p.N / C1_WGRAD_CG == 4;
     dim3 grid(p.nsplit, p.ndim == 3 ? 3 : 1);
-    if (dtype) hipLaunchKernelGGL(c1_s2_wgrad_kernel<BF16>, grid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL(c1_s2_wgrad_kernel<F32>, grid, dim3(256), lds, st, p);
+#define C1W_CASE(TR, Q)                                                                   \
+    do {                                                                                  \
+        if (int rc = small_lds(c1_s2_wgrad_kernel<TR, Q>, lds)) return rc;                \
+        hipLaunchKernelGGL((c1_s2_wgrad_kernel<TR, Q>), grid, dim3(256), lds, st, p);     \
+    } while (0)
+    if (dtype) { if (quad) C1W_CASE(BF16, true); else C1W_CASE(BF16, false); }
+    else { if (quad) C1W_CASE(F32, true); else C1W_CASE(F32, false); }
+#undef C1W_CASE
     return check_launch("c1_s2_wgrad");
 }
 
