@@ -27,11 +27,6 @@ __global__ __launch_bounds__(256) void c1_s2_fwd_kernel(const C1Params p) {
     const int ppb = 256 / G;
     float* wl = sm;
     float* sst = sm + N * KK;
-    for (int i = threadIdx.x; i < N * KK; i += 256) {
-        const int n = i / KK, k = i - n * KK;
-        wl[k * N + n] = (n < p.n_w1) ? p.w[n * KK + k] : p.w2[(n - p.n_w1) * KK + k];
-    }
-    __syncthreads();
     const int grp = threadIdx.x % G, pl = threadIdx.x / G;
     const int cz = blockIdx.z % p.cd[0], img = blockIdx.z / p.cd[0];
     const int cx = blockIdx.x * ppb + pl;
@@ -39,6 +34,28 @@ __global__ __launch_bounds__(256) void c1_s2_fwd_kernel(const C1Params p) {
     const size_t fpix = (size_t)p.fd[0] * p.fd[1] * p.fd[2];
     const size_t cpix = (size_t)p.cd[0] * p.cd[1] * p.cd[2];
     const float* xin = p.x1 + (size_t)img * fpix;
+    // the input values of one (row group, kz plane): (2*ROWS+1) x 3 independent loads
+    auto load_rows = [&](int cy0, int fz, float (*xr)[3]) {
+#pragma unroll
+        for (int j = 0; j < 2 * ROWS + 1; ++j) {
+            const int fy = 2 * cy0 - 1 + j;
+            const bool rok = lane_ok && (unsigned)fy < (unsigned)p.fd[1];
+            const float* row = xin + ((size_t)fz * p.fd[1] + (rok ? fy : 0)) * p.fd[2];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int fx = 2 * cx - 1 + kx;
+                xr[j][kx] = (rok && (unsigned)fx < (unsigned)p.fd[2]) ? row[fx] : 0.f;
+            }
+        }
+    };
+    // 2-D: the first row group's inputs are requested before the weights are staged, so the two round trips overlap
+    float xr0[2 * ROWS + 1][3];
+    if (KZ == 1) load_rows(blockIdx.y * C1F_YG * ROWS, 0, xr0);
+    for (int i = threadIdx.x; i < N * KK; i += 256) {
+        const int n = i / KK, k = i - n * KK;
+        wl[k * N + n] = (n < p.n_w1) ? p.w[n * KK + k] : p.w2[(n - p.n_w1) * KK + k];
+    }
+    __syncthreads();
     float bv[8], s1[8], s2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -60,16 +77,13 @@ __global__ __launch_bounds__(256) void c1_s2_fwd_kernel(const C1Params p) {
         const int fz = (KZ == 3) ? 2 * cz - 1 + kz : 0;
         if ((unsigned)fz >= (unsigned)p.fd[0]) continue;   // uniform over the workgroup
         float xr[2 * ROWS + 1][3];
+        if (KZ == 1 && yg == 0) {
 #pragma unroll
-        for (int j = 0; j < 2 * ROWS + 1; ++j) {
-            const int fy = 2 * cy0 - 1 + j;
-            const bool rok = lane_ok && (unsigned)fy < (unsigned)p.fd[1];
-            const float* row = xin + ((size_t)fz * p.fd[1] + (rok ? fy : 0)) * p.fd[2];
+            for (int j = 0; j < 2 * ROWS + 1; ++j)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int fx = 2 * cx - 1 + kx;
-                xr[j][kx] = (rok && (unsigned)fx < (unsigned)p.fd[2]) ? row[fx] : 0.f;
-            }
+                for (int kx = 0; kx < 3; ++kx) xr[j][kx] = xr0[j][kx];
+        } else {
+            load_rows(cy0, fz, xr);
         }
         // weights of one tap at a time from LDS (two 16-byte reads): keeps the register count low enough
         // for six waves per SIMD, which is what hides the latency of the gather loads
