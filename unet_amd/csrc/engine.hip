@@ -44,7 +44,7 @@ struct Reloc { size_t field_off; int base; };
 
 struct AddArgs { char* dst; int dpitch, dcoff; const char* src; int spitch, scoff, c; long long npix; };
 struct MemsetArgs { char* ptr; size_t bytes; };
-struct TabArgs { int first, count, max_elems; };   // max_elems: packs: largest element count; reductions: workgroups of the launch
+struct TabArgs { int first, count, max_elems; };   // max_elems: workgroups of the table launch
 
 struct Step {
     int kind = 0, dtype = 0, bucket = 0;
@@ -907,9 +907,13 @@ bool build(mi_unet& u) {
         if (s.kind == K_PACK) {
             s.tab.first = 0; s.tab.count = (int)u.packs.size();  // forward and backward packs in one launch
             if (!train) s.tab.count = n_fwd_packs;
-            int mx = 1;
-            for (int i = 0; i < s.tab.count; ++i) { const int e = u.packs[i].ntaps * u.packs[i].N * u.packs[i].K; if (e > mx) mx = e; }
-            s.tab.max_elems = mx;
+            int blk = 0;
+            for (int i = 0; i < s.tab.count; ++i) {
+                PackDesc& d = u.packs[i];
+                d.blk0 = blk; d.nblk = pack_blocks_for(d.N * d.K);
+                blk += d.nblk;
+            }
+            s.tab.max_elems = blk;
         }
         if (s.kind == K_MEMSET) s.ms.bytes = align_up(B.stats_cursor, 16);
     }

@@ -938,7 +938,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ void reduce_body(const ReduceDesc& d, int blk, int nblk);
 template <class TR>
-__device__ __forceinline__ void pack_body(const PackDesc& d);
+__device__ __forceinline__ void pack_body(const PackDesc& d, int blk, int nblk);
 // one launch for a table of descriptors: workgroup b serves the descriptor whose range [blk0, blk0 + nblk) holds b
 __global__ __launch_bounds__(256) void reduce_kernel(const ReduceDesc* __restrict__ descs, int ndesc) {
     int i = 0;
@@ -946,9 +946,10 @@ __global__ __launch_bounds__(256) void reduce_kernel(const ReduceDesc* __restric
     reduce_body(descs[i], (int)blockIdx.x - descs[i].blk0, descs[i].nblk);
 }
 template <class TR>
-__global__ __launch_bounds__(256) void pack_kernel(const PackDesc* __restrict__ descs) {
-    const PackDesc d = descs[blockIdx.y];
-    pack_body<TR>(d);
+__global__ __launch_bounds__(256) void pack_kernel(const PackDesc* __restrict__ descs, int ndesc) {
+    int i = 0;
+    while (i + 1 < ndesc && (int)blockIdx.x >= descs[i + 1].blk0) ++i;
+    pack_body<TR>(descs[i], (int)blockIdx.x - descs[i].blk0, descs[i].nblk);
 }
 
 // 256 threads = EL output elements x SG slab groups (EL = 64, 16, 4 or 1: few outputs with many slabs get more
@@ -1006,21 +1007,33 @@ __device__ __forceinline__ void reduce_body(const ReduceDesc& d, int blk, int nb
 }
 __global__ __launch_bounds__(256) void reduce_one_kernel(const ReduceDesc d) { reduce_body(d, blockIdx.x, gridDim.x); }
 
+// A thread takes one (n, k) pair and walks its taps: the taps of a pair are neighbours in the source (one or two
+// cache lines, fetched once), and for every tap the lanes of a wave write consecutive k.
 template <class TR>
-__device__ __forceinline__ void pack_body(const PackDesc& d) {
-    const int total = d.ntaps * d.N * d.K;
+__device__ __forceinline__ void pack_body(const PackDesc& d, int blk, int nblk) {
+    const int pairs = d.N * d.K;
     typename TR::elem* dst = reinterpret_cast<typename TR::elem*>(d.dst);
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        const int k = i % d.K; const int r = i / d.K;
-        const int n = r % d.N; const int t = r / d.N;
-        const float v = d.src[(size_t)n * d.sn + (size_t)k * d.sk + d.kidx[t]];
-        const size_t o = ((size_t)t * d.Ntot + d.n_off + n) * d.Ktot + d.k_off + k;
-        if (TR::ESZ == 2) dst[o] = f32_to_bf16(v);
-        else reinterpret_cast<float*>(dst)[o] = v;
+    for (int i = blk * 256 + threadIdx.x; i < pairs; i += nblk * 256) {
+        const int n = i / d.K; const int k = i - n * d.K;
+        const float* src = d.src + (size_t)n * d.sn + (size_t)k * d.sk;
+        const size_t o0 = (size_t)(d.n_off + n) * d.Ktot + d.k_off + k;
+        const size_t ot = (size_t)d.Ntot * d.Ktot;
+        for (int t0 = 0; t0 < d.ntaps; t0 += 9) {
+            float v[9];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) v[j] = t0 + j < d.ntaps ? src[d.kidx[t0 + j]] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                if (t0 + j >= d.ntaps) break;
+                const size_t o = o0 + (size_t)(t0 + j) * ot;
+                if (TR::ESZ == 2) dst[o] = f32_to_bf16(v[j]);
+                else reinterpret_cast<float*>(dst)[o] = v[j];
+            }
+        }
     }
 }
 template <class TR>
-__global__ __launch_bounds__(256) void pack_one_kernel(const PackDesc d) { pack_body<TR>(d); }
+__global__ __launch_bounds__(256) void pack_one_kernel(const PackDesc d) { pack_body<TR>(d, blockIdx.x, gridDim.x); }
 
 template <class K>
 int set_lds(K kern, size_t bytes) {
@@ -1308,13 +1321,17 @@ int launch_reduce(const ReduceDesc* d_descs, int ndesc, int total_blocks, hipStr
     return 0;
 }
 
-int launch_pack(int dtype, const PackDesc* d_descs, int ndesc, int max_elems, hipStream_t st) {
-    if (ndesc <= 0) return 0;
-    int gx = (max_elems + 255) / 256;
-    if (gx > 64) gx = 64;
-    if (gx < 1) gx = 1;
-    if (dtype) hipLaunchKernelGGL(pack_kernel<BF16>, dim3(gx, ndesc), dim3(256), 0, st, d_descs);
-    else hipLaunchKernelGGL(pack_kernel<F32>, dim3(gx, ndesc), dim3(256), 0, st, d_descs);
+// workgroups for a descriptor of `pairs` (n, k) pairs: one pair per thread
+int pack_blocks_for(int pairs) {
+    const int g = (pairs + 255) / 256;
+    return g < 1 ? 1 : g > 1024 ? 1024 : g;
+}
+
+// total_blocks: sum of the descriptors' nblk (each set from pack_blocks_for(), blk0 = running sum)
+int launch_pack(int dtype, const PackDesc* d_descs, int ndesc, int total_blocks, hipStream_t st) {
+    if (ndesc <= 0 || total_blocks <= 0) return 0;
+    if (dtype) hipLaunchKernelGGL(pack_kernel<BF16>, dim3(total_blocks), dim3(256), 0, st, d_descs, ndesc);
+    else hipLaunchKernelGGL(pack_kernel<F32>, dim3(total_blocks), dim3(256), 0, st, d_descs, ndesc);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { mi_set_error(std::string("pack launch: ") + hipGetErrorString(e)); return -2; }
     return 0;
@@ -1329,8 +1346,7 @@ int launch_reduce_one(const ReduceDesc& d, hipStream_t st) {
 }
 
 int launch_pack_one(int dtype, const PackDesc& d, hipStream_t st) {
-    int total = d.ntaps * d.N * d.K;
-    int gx = (total + 255) / 256; if (gx > 256) gx = 256; if (gx < 1) gx = 1;
+    int gx = (d.N * d.K + 255) / 256; if (gx > 256) gx = 256; if (gx < 1) gx = 1;
     if (dtype) hipLaunchKernelGGL(pack_one_kernel<BF16>, dim3(gx), dim3(256), 0, st, d);
     else hipLaunchKernelGGL(pack_one_kernel<F32>, dim3(gx), dim3(256), 0, st, d);
     hipError_t e = hipGetLastError();

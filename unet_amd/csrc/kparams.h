@@ -74,6 +74,7 @@ struct PackDesc {
     const float* src; void* dst;
     int N, K, ntaps, sn, sk, Ntot, Ktot, n_off, k_off;
     int kidx[MI_MAX_TAPS];
+    int blk0, nblk;                         // table launches: this descriptor owns workgroups [blk0, blk0 + nblk) of its launch
 };
 
 // Instance-norm + PReLU (+dropout, +residual) launch
@@ -137,7 +138,8 @@ int launch_igemm(int dtype, const IgemmParams& p, hipStream_t st);
 int launch_wgrad(int dtype, const WgradParams& p, hipStream_t st);
 int launch_reduce(const ReduceDesc* d_descs, int ndesc, int total_blocks, hipStream_t st);
 int reduce_blocks_for(int total);
-int launch_pack(int dtype, const PackDesc* d_descs, int ndesc, int max_elems, hipStream_t st);
+int launch_pack(int dtype, const PackDesc* d_descs, int ndesc, int total_blocks, hipStream_t st);
+int pack_blocks_for(int pairs);
 int launch_reduce_one(const ReduceDesc& d, hipStream_t st);
 int c1_wgrad_slabs(int N, const int cd[3]);
 void igemm_parallelism(int dtype, const IgemmParams& p, long long* wgs, int* nkc);
