@@ -19,21 +19,58 @@ __device__ __forceinline__ float load_label(const void* t, int tdtype, size_t i,
     return v;
 }
 
+// W consecutive elements starting at element i (a multiple of W): logits and labels.  W = 4 needs 16-byte
+// aligned logits (and labels of the same width where they are loaded as one vector).
+template <int W>
+__device__ __forceinline__ void load_w(const float* z, size_t i, float* v) {
+    if constexpr (W == 4) { const float4 q = *reinterpret_cast<const float4*>(z + i); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+    else v[0] = z[i];
+}
+template <int W>
+__device__ __forceinline__ void load_labels(const void* t, int tdtype, size_t i, int fold2, float* v) {
+    if constexpr (W == 4) {
+        if (tdtype == 0) load_w<4>(reinterpret_cast<const float*>(t), i, v);
+        else if (tdtype == 1) {
+            const uchar4 q = *reinterpret_cast<const uchar4*>(reinterpret_cast<const unsigned char*>(t) + i);
+            v[0] = (float)q.x; v[1] = (float)q.y; v[2] = (float)q.z; v[3] = (float)q.w;
+        } else if (tdtype == 3) {
+            const int4 q = *reinterpret_cast<const int4*>(reinterpret_cast<const int*>(t) + i);
+            v[0] = (float)q.x; v[1] = (float)q.y; v[2] = (float)q.z; v[3] = (float)q.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (float)reinterpret_cast<const long long*>(t)[i + j];
+        }
+        if (fold2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = v[j] == 2.0f ? 1.0f : v[j];
+        }
+    } else {
+        v[0] = load_label(t, tdtype, i, fold2);
+    }
+}
+
 // sums[b] = { sum p*t, sum p, sum t, sum bce }  with p = sigmoid(z)
+template <int W>
 __global__ __launch_bounds__(256) void loss_reduce_kernel(const LossParams p) {
     __shared__ float red[4][4];
     const int b = blockIdx.y;
-    const float* z = p.logits + (size_t)b * p.npix;
+    const size_t base = (size_t)b * p.npix;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < p.npix; i += gridDim.x * 256) {
-        const float zi = z[i];
-        const float t = load_label(p.target, p.tdtype, (size_t)b * p.npix + i, p.fold2);
-        const float e = __expf(-fabsf(zi));
-        const float inv = __frcp_rn(1.f + e);
-        const float s = zi >= 0.f ? inv : e * inv;
-        a0 += s * t; a1 += s; a2 += t;
-        // log(1 + e) for e in (0, 1]: the series below 2^-12 keeps the relative accuracy log1p would give
-        a3 += fmaxf(zi, 0.f) - zi * t + (e < 2.44140625e-4f ? e * (1.f - 0.5f * e) : __logf(1.f + e));
+    const int ng = p.npix / W;
+    for (int g = blockIdx.x * 256 + threadIdx.x; g < ng; g += gridDim.x * 256) {
+        float zv[W], tv[W];
+        load_w<W>(p.logits, base + (size_t)g * W, zv);
+        load_labels<W>(p.target, p.tdtype, base + (size_t)g * W, p.fold2, tv);
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            const float zi = zv[j], t = tv[j];
+            const float e = __expf(-fabsf(zi));
+            const float inv = __frcp_rn(1.f + e);
+            const float s = zi >= 0.f ? inv : e * inv;
+            a0 += s * t; a1 += s; a2 += t;
+            // log(1 + e) for e in (0, 1]: the series below 2^-12 keeps the relative accuracy log1p would give
+            a3 += fmaxf(zi, 0.f) - zi * t + (e < 2.44140625e-4f ? e * (1.f - 0.5f * e) : __logf(1.f + e));
+        }
     }
     a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
     const int w = threadIdx.x >> 6;
@@ -45,36 +82,47 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const LossParams p) {
 }
 
 // loss = lambda_dice * mean_b(1 - (2I+snr)/(P+T+sdr)) + lambda_ce * sum_b(bce) / (nb*npix)
+// one wave: lane l takes samples l, l + 64, ..., the lanes are combined by a fixed butterfly
 __global__ void loss_finalize_kernel(const LossParams p) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double dice = 0.0, ce = 0.0;
-    for (int b = 0; b < p.nb; ++b) {
+    for (int b = threadIdx.x; b < p.nb; b += 64) {
         const double* s = p.sums + b * 4;
         dice += 1.0 - (2.0 * s[0] + (double)p.smooth_nr) / (s[1] + s[2] + (double)p.smooth_dr);
         ce += s[3];
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { dice += __shfl_xor(dice, o, 64); ce += __shfl_xor(ce, o, 64); }
+    if (threadIdx.x != 0) return;
     const float l = (float)((double)p.lambda_dice * dice / (double)p.nb + (double)p.lambda_ce * ce / ((double)p.nb * (double)p.npix));
     p.loss[0] = l;
     if (p.loss_accum) p.loss_accum[0] += l;
 }
 
 // dz = g * [ lambda_dice/nb * (-2 t D + (2I+snr)) / D^2 * s(1-s) + lambda_ce * (s - t)/(nb*npix) ],  D = P+T+sdr
+template <int W>
 __global__ __launch_bounds__(256) void loss_bwd_kernel(const LossParams p) {
     const int b = blockIdx.y;
-    const float* z = p.logits + (size_t)b * p.npix;
-    float* dz = p.dlogits + (size_t)b * p.npix;
+    const size_t base = (size_t)b * p.npix;
     const float g = (p.gout ? p.gout[0] : 1.f) * p.gscale;
     const double* sm = p.sums + b * 4;
     const float D = (float)(sm[1] + sm[2] + (double)p.smooth_dr);
     const float num = (float)(2.0 * sm[0] + (double)p.smooth_nr);
     const float cd = g * p.lambda_dice / ((float)p.nb * D * D);
     const float cc = g * p.lambda_ce / ((float)p.nb * (float)p.npix);
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < p.npix; i += gridDim.x * 256) {
-        const float zi = z[i];
-        const float t = load_label(p.target, p.tdtype, (size_t)b * p.npix + i, p.fold2);
-        const float e = __expf(-fabsf(zi));
-        const float s = zi >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
-        dz[i] = cd * (num - 2.f * t * D) * s * (1.f - s) + cc * (s - t);
+    const int ng = p.npix / W;
+    for (int g = blockIdx.x * 256 + threadIdx.x; g < ng; g += gridDim.x * 256) {
+        float zv[W], tv[W], o[W];
+        load_w<W>(p.logits, base + (size_t)g * W, zv);
+        load_labels<W>(p.target, p.tdtype, base + (size_t)g * W, p.fold2, tv);
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            const float zi = zv[j], t = tv[j];
+            const float e = __expf(-fabsf(zi));
+            const float s = zi >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+            o[j] = cd * (num - 2.f * t * D) * s * (1.f - s) + cc * (s - t);
+        }
+        if constexpr (W == 4) *reinterpret_cast<float4*>(p.dlogits + base + (size_t)g * W) = make_float4(o[0], o[1], o[2], o[3]);
+        else p.dlogits[base + (size_t)g] = o[0];
     }
 }
 
@@ -221,17 +269,26 @@ int grid_for(long long n, int per_block, int cap) {
 
 }  // namespace
 
+// four pixels per lane: every sample starts on a 16-byte boundary of the logits and on a vector boundary of the labels
+static bool loss_v4(const LossParams& p) {
+    const int tsz = p.tdtype == 1 ? 1 : p.tdtype == 2 ? 8 : 4;
+    return p.npix % 4 == 0 && ((uintptr_t)p.logits & 15) == 0 && ((uintptr_t)p.target & (uintptr_t)(4 * tsz > 16 ? 15 : 4 * tsz - 1)) == 0;
+}
+
 // sums ([nb][4] doubles) is zeroed here, then filled; loss[0] is written; loss_accum (optional) is accumulated.
 int launch_loss_fwd(const LossParams& p, hipStream_t st) {
     MI_HIP(hipMemsetAsync(p.sums, 0, (size_t)p.nb * 4 * sizeof(double), st));
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(grid_for(p.npix, 2048, 128), p.nb), dim3(256), 0, st, p);
+    if (loss_v4(p)) hipLaunchKernelGGL(loss_reduce_kernel<4>, dim3(grid_for(p.npix, 2048, 128), p.nb), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(loss_reduce_kernel<1>, dim3(grid_for(p.npix, 2048, 128), p.nb), dim3(256), 0, st, p);
     if (int r = check_launch("loss_reduce")) return r;
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, p);
     return check_launch("loss_finalize");
 }
 
 int launch_loss_bwd(const LossParams& p, hipStream_t st) {
-    hipLaunchKernelGGL(loss_bwd_kernel, dim3(grid_for(p.npix, 1024, 256), p.nb), dim3(256), 0, st, p);
+    if (loss_v4(p) && ((uintptr_t)p.dlogits & 15) == 0)
+        hipLaunchKernelGGL(loss_bwd_kernel<4>, dim3(grid_for(p.npix, 2048, 256), p.nb), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(loss_bwd_kernel<1>, dim3(grid_for(p.npix, 1024, 256), p.nb), dim3(256), 0, st, p);
     return check_launch("loss_bwd");
 }
 
