@@ -1,6 +1,7 @@
 """Network-level parity on the GPU: logits, loss and all 63 gradients of the HIP engine against the
 CPU oracle on identical seeds and synthetic inputs (fp32: 1e-4 relative; bf16: loose bound), plus
 loss / metric / optimizer / sliding-window parity and the fused trainer."""
+import copy
 import math
 
 import pytest
@@ -67,6 +68,8 @@ CONFIGS = [
     (3, (16, 32), 2, 1, (16, 16, 16)),
     (3, (16, 32, 64, 128, 256), 2, 1, (32, 32, 32)),
     (2, (32, 32), 2, 1, (16, 16)),
+    (2, (16, 32, 64, 128), 2, 3, (80, 112)),        # ragged: partial 16 x 16 tiles at every level, odd batch
+    (3, (16, 32, 64), 2, 2, (16, 32, 48)),          # non-cubic volume
 ]
 
 
@@ -105,6 +108,15 @@ def test_fp32_logits_loss_and_gradients_match_oracle(dev, cfg):
     assert rel_err(ym, yo) < 1e-4, "logits"
     assert abs(float(lm) - float(lo)) < 1e-5 * max(1.0, abs(float(lo))), "loss"
     bad = [(n, e) for n, e in grad_errors(o, m) if e > 1e-4]
+    if bad:
+        # A slope gradient is one scalar summed over a whole tensor with both signs: when the terms cancel, the
+        # fp32 oracle itself is off by more than 1e-4 of the result.  Such tensors are judged against the same
+        # oracle evaluated in fp64.
+        o64 = copy.deepcopy(o).double()
+        o64.zero_grad()
+        oracle.DiceCELoss(sigmoid=True)(o64(x.double()), t.double()).backward()
+        err64 = dict(grad_errors(o64, m))
+        bad = [(n, e, err64[n]) for n, e in bad if not (n.endswith("adn.A.weight") and err64[n] < 1e-4)]
     assert not bad, bad
 
 
