@@ -6,7 +6,8 @@
 * the loss of a batch is the mean of the losses of its halves (Dice and BCE are means over samples / pixels);
 * a sliding window as large as the image is the plain forward pass;
 * the directional derivative of the loss along a random direction matches <gradient, direction> (fp32);
-* one fused trainer step equals forward + loss + backward + AdamW done through autograd.
+* one fused trainer step equals forward + loss + backward + AdamW done through autograd;
+* the 3-D benchmark shape (4 patches of 96^3): batch permutation and directional derivative.
 """
 import pytest
 import torch
@@ -109,3 +110,34 @@ def test_fused_step_equals_autograd_step_fp32(dev):
     torch.cuda.synchronize()
     # AdamW turns rounding-level gradients into +-lr steps: one step of lr = 1e-3
     assert float((ma.flat_parameters() - mb.flat_parameters()).abs().max()) < 2.5e-3
+
+
+def test_3d_patch_permutation_and_direction_full_size(dev):
+    """The 3-D benchmark shape (4 patches of 96^3, channels 16-256): permuting the batch permutes the logits bit
+    for bit (bf16), and the fp32 gradient agrees with a central difference of the loss along a random direction."""
+    torch.manual_seed(0)
+    mk = lambda dt: unet_amd.UNet(3, 1, 1, CH, (2, 2, 2, 2), num_res_units=2, compute_dtype=dt).to(dev)
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(4, 1, 96, 96, 96, generator=g).to(dev)
+    t = disks(4, (96, 96, 96), 6, with_two=True).to(dev)
+    loss = unet_amd.DiceCELoss(sigmoid=True, fold_label_two=True)
+    m = mk(torch.bfloat16).train()
+    perm = torch.tensor([2, 0, 3, 1], device=dev)
+    with torch.no_grad():
+        y = m(x); yp = m(x[perm])
+    assert torch.equal(yp, y[perm])
+    del m, y, yp
+    m = mk(torch.float32).eval()
+    l0 = loss(m(x), t); l0.backward()
+    ps = list(m.parameters())
+    dirs = [torch.randn(p.shape, generator=g).to(dev) * p.detach().abs().mean().clamp(min=1e-3) for p in ps]
+    dot = sum(float((p.grad.double() * d.double()).sum()) for p, d in zip(ps, dirs))
+    eps = 1e-2
+    vals = []
+    with torch.no_grad():
+        for sgn in (1.0, -1.0):
+            for p, d in zip(ps, dirs): p.add_(sgn * eps * d)
+            vals.append(float(loss(m(x), t).double()))
+            for p, d in zip(ps, dirs): p.sub_(sgn * eps * d)
+    fd = (vals[0] - vals[1]) / (2 * eps)
+    assert abs(fd - dot) < 2e-2 * max(abs(dot), 1e-3), (fd, dot)
