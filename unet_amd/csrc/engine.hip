@@ -265,6 +265,7 @@ struct Builder {
         return true;
     }
 
+    int wgrad_target = 0;      // workgroups wanted for the next weight gradients (0: the default)
     // weight-gradient step; returns slab offsets through the reduce descriptors the caller adds
     void add_wgrad(const std::string& layer, const ConvShape& cs, const Ten& f0, int f0_c, const Ten* f1, int F,
                    const Ten& sten, int S, size_t* partial_off, size_t* pbias_off, int* nslab, int* ntaps) {
@@ -276,7 +277,7 @@ struct Builder {
         if (f1) { REL(s, p, f1, f1->base, f1->off); p.f1_pitch = f1->pitch; p.f1_coff = f1->coff; }
         REL(s, p, s, sten.base, sten.off); p.s_pitch = sten.pitch; p.s_coff = sten.coff;
         int ff, sf, wf, wsn;
-        wgrad_choose_split(u.dt, p);
+        wgrad_choose_split(u.dt, p, wgrad_target);
         wgrad_config(u.dt, p, &ff, &sf, &wf, &wsn);
         const int slabs = wgrad_slabs(u.dt, p);
         const size_t po = alloc((size_t)slabs * p.ntaps_total * F * S * sizeof(float));
@@ -816,6 +817,8 @@ bool build(mi_unet& u) {
             const std::string P = dprefix[l];
             const std::string lname = "down" + std::to_string(l);
             DownSave& D = down[l];
+            // the last weight gradients run largely after the main chain has ended, with less to slow down: one workgroup per CU
+            B.wgrad_target = l == 0 ? (getenv("MI_WG_TAIL") ? atoi(getenv("MI_WG_TAIL")) : 256) : 0;
             Ten dout = gcatA[l];
             Ten g_raw = B.new_tensor(l + 1, cout, esz);
             B.add_norm_bwd(lname + ".unit" + std::to_string(R - 1) + " norm+prelu bwd", l + 1, cout, dt, dout, D.un[R - 1].raw,

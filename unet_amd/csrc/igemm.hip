@@ -1232,12 +1232,14 @@ void wgrad_config(int dtype, const WgradParams& p, int* ff, int* sf, int* wf, in
 
 // Chooses how many workgroups split the pixels of each (F block, S block, tap group): enough workgroups to
 // fill the chip, never more than there are tiles.
-void wgrad_choose_split(int dtype, WgradParams& p) {
+void wgrad_choose_split(int dtype, WgradParams& p, int target) {
     int ff, sf, wf, wsn;
     p.nsplit = 1;
     wgrad_config(dtype, p, &ff, &sf, &wf, &wsn);
     const int blocks = (p.F / (16 * ff * wf)) * (p.S / (16 * sf * wsn)) * p.ntapg;
-    int target = 256;
+    // default: three quarters of the CUs.  A weight gradient runs next to the kernels of the critical chain; with
+    // more workgroups it finishes sooner and slows them by more than it gains (measured 192 < 256 << 512).
+    if (target <= 0) target = 192;
     if (const char* e = getenv("MI_WG_WGS")) { const int v = atoi(e); if (v > 0) target = v; }
     int nsplit = (target + blocks - 1) / blocks;
     if (nsplit > p.tiles_total) nsplit = p.tiles_total;

@@ -144,7 +144,7 @@ int launch_reduce_one(const ReduceDesc& d, hipStream_t st);
 int c1_wgrad_slabs(int N, const int cd[3]);
 void igemm_parallelism(int dtype, const IgemmParams& p, long long* wgs, int* nkc);
 int launch_ksplit_finish(int dtype, const IgemmParams& p, hipStream_t st);
-void wgrad_choose_split(int dtype, WgradParams& p);
+void wgrad_choose_split(int dtype, WgradParams& p, int target = 0);   // target: workgroups wanted, 0 = default
 int launch_pack_one(int dtype, const PackDesc& d, hipStream_t st);
 int launch_norm_fwd(int dtype, const NormParams& p, hipStream_t st);
 int launch_norm_bwd(int dtype, const NormParams& p, hipStream_t st);
