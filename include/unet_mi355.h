@@ -3,7 +3,7 @@
  * The reference (hakkini2/UNet) has no FFI of its own: train.py reaches its arithmetic
  * through the Python surface of MONAI / PyTorch.  Every entry point below therefore cites
  * the reference call site whose work it takes over; the Python package `unet_amd` binds
- * these symbols with ctypes.
+ * these symbols with ctypes (unet_amd/_lib.py lists every prototype).
  *
  * Conventions
  *  - plain C types only; device buffers are raw pointers (torch `tensor.data_ptr()`),
