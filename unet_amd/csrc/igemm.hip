@@ -380,6 +380,10 @@ template <class TR, int CPS, int NFRAG, int KS, int SA, bool PHL>
 __global__ __launch_bounds__(256) void igemm2d_kernel(const IgemmParams p) {
     constexpr int ESZ = TR::ESZ;
     constexpr int KCB = CPS * 16, KCE = KCB / ESZ, PITCH = KCB + 16, NT = NFRAG * 16;
+    // weight image: 32-byte rows are stored without padding, the two 16-byte halves of a row swapped in every
+    // other group of eight rows (the 16 lanes of a fragment read then hit 16 different bank groups); a third
+    // less LDS than padded rows, which is what lets two workgroups with a 33 x 33 patch share a CU
+    constexpr int WPITCH = CPS == 2 ? KCB : PITCH;
     constexpr int PD = KS == 3 ? 15 * SA + 3 : KS == 2 ? 17 : 16;
     constexpr int PP = PD * PD, TOTAL = PP * CPS, NSLOT = (TOTAL + 255) / 256;
     // PHL (KS = 2 only): one workgroup computes all four scatter phases from one staged patch
@@ -442,7 +446,11 @@ __global__ __launch_bounds__(256) void igemm2d_kernel(const IgemmParams p) {
         }
 #pragma unroll
         for (int u = 0; u < MAXW; ++u)
-            if ((int)(w_d[u] >> 27) < ntap_pad) *reinterpret_cast<uint4*>(smW + lo0 + u * RSTEP) = v[u];
+            if ((int)(w_d[u] >> 27) < ntap_pad) {
+                const int row = tid / CPS + u * (256 / CPS);
+                const int cw = CPS == 2 ? (cc_s ^ ((row >> 3) & 1)) : cc_s;
+                *reinterpret_cast<uint4*>(smW + row * WPITCH + cw * 16) = v[u];
+            }
     };
     if (w_once) stage_weights(0);
     int toffs[MAXTAP];
@@ -513,7 +521,7 @@ __global__ __launch_bounds__(256) void igemm2d_kernel(const IgemmParams p) {
                             bfr[mf] = *reinterpret_cast<const uint4*>(smA + a_base0 + mf * SA * PD * PITCH + toffs[t] + g * 16);
 #pragma unroll
                         for (int nf = 0; nf < NFRAG; ++nf)
-                            afr[nf] = *reinterpret_cast<const uint4*>(smW + ((t * NT + nf * 16 + lr) * PITCH) + g * 16);
+                            afr[nf] = *reinterpret_cast<const uint4*>(smW + ((t * NT + nf * 16 + lr) * WPITCH) + g * 16);
 #pragma unroll
                         for (int mf = 0; mf < 4; ++mf)
 #pragma unroll
@@ -538,7 +546,8 @@ __global__ __launch_bounds__(256) void igemm2d_kernel(const IgemmParams p) {
                         bfr[mf] = *reinterpret_cast<const uint4*>(smA + a_base0 + mf * SA * PD * PITCH + toff + cc * 16);
 #pragma unroll
                     for (int nf = 0; nf < NFRAG; ++nf)
-                        afr[nf] = *reinterpret_cast<const uint4*>(smW + ((tl * NT + nf * 16 + lr) * PITCH) + cc * 16);
+                        afr[nf] = *reinterpret_cast<const uint4*>(smW + ((tl * NT + nf * 16 + lr) * WPITCH) +
+                                                                  (CPS == 2 ? (cc ^ ((lr >> 3) & 1)) : cc) * 16);
 #pragma unroll
                     for (int mf = 0; mf < 4; ++mf)
 #pragma unroll
@@ -1097,7 +1106,8 @@ int launch_igemm2d_t(const IgemmParams& pin, hipStream_t st) {
         for (int t = 1; t <= want; ++t) if (p.ntile[2] % t == 0) tpw = t;
         p.tpw = tpw;
     }
-    size_t lds = (size_t)PD * PD * PITCH + (size_t)TAPPAD * NT * PITCH;
+    constexpr int WPITCH = CPS == 2 ? CPS * 16 : PITCH;     // unpadded, swizzled weight rows (see the kernel)
+    size_t lds = (size_t)PD * PD * PITCH + (size_t)TAPPAD * NT * WPITCH;
     if (lds < (size_t)NT * 2 * 4 * 4) lds = NT * 2 * 4 * 4;
     auto kern = igemm2d_kernel<TR, CPS, NFRAG, KS, SA, PHL>;
     if (int r = set_lds(kern, lds)) return r;
