@@ -376,8 +376,10 @@ __device__ __forceinline__ float row_sum16(float v) {
 // one LDS base and one output offset; a workgroup walks `tpw` consecutive tiles of one image row, keeps
 // its staging descriptors in registers, stages the weight image once when a single staging covers it
 // and reduces the statistics partials once.
+// The phase-loop variants keep four accumulator sets; left alone the compiler spends 184 / 328 registers on them
+// (two / one workgroup per CU), under a cap it fits 144 / 218 without spilling (three / two).
 template <class TR, int CPS, int NFRAG, int KS, int SA, bool PHL>
-__global__ __launch_bounds__(256) void igemm2d_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHL ? (NFRAG == 1 ? 3 : 2) : 1))) void igemm2d_kernel(const IgemmParams p) {
     constexpr int ESZ = TR::ESZ;
     constexpr int KCB = CPS * 16, KCE = KCB / ESZ, PITCH = KCB + 16, NT = NFRAG * 16;
     // weight image: 32-byte rows are stored without padding, the two 16-byte halves of a row swapped in every
