@@ -309,12 +309,12 @@ template <class TR, bool QUAD>
 __global__ __launch_bounds__(256) void c1_s2_wgrad_kernel(const C1Params p) {
     constexpr int ESZ = TR::ESZ;
     constexpr int CG = C1_WGRAD_CG;   // channels per thread: few registers, many waves per SIMD
-    extern __shared__ __attribute__((aligned(16))) float sm[];  // [4 waves][N][10]
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // [4 waves (16 rows: QUAD)][N][10]
     const int KZ = p.ndim == 3 ? 3 : 1;
     const int KK = KZ * 9;
     const int kz = blockIdx.y;
     const int G = p.N / CG;
-    for (int i = threadIdx.x; i < 4 * p.N * 10; i += 256) sm[i] = 0.f;
+    for (int i = threadIdx.x; i < (QUAD ? 16 : 4) * p.N * 10; i += 256) sm[i] = 0.f;
     __syncthreads();
     const size_t cpix = (size_t)p.cd[0] * p.cd[1] * p.cd[2];
     const size_t fpix = (size_t)p.fd[0] * p.fd[1] * p.fd[2];
@@ -408,7 +408,25 @@ __global__ __launch_bounds__(256) void c1_s2_wgrad_kernel(const C1Params p) {
     (void)cpix;
     // lanes that share a channel group: xor-reduce over lane bits >= log2(G) when G divides the wave
     const bool pow2 = (64 % G) == 0;
-    if (pow2) {
+    constexpr int NIMG = QUAD ? 16 : 4;      // LDS images summed at the end: one per 16-lane row (QUAD) or per wave
+    if (QUAD) {
+        // four channel groups per pixel: the partner lanes inside a 16-lane row are 4 and 8 away, which two
+        // DPP row shifts add up in lanes 12..15; every row then writes its own LDS image
+#pragma unroll
+        for (int e = 0; e < CG; ++e) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                float a = acc[e][k];
+                a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x114, 0xf, 0xf, true));
+                a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x118, 0xf, 0xf, true));
+                acc[e][k] = a;
+            }
+            float b = accb[e];
+            b += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(b), 0x114, 0xf, 0xf, true));
+            b += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(b), 0x118, 0xf, 0xf, true));
+            accb[e] = b;
+        }
+    } else if (pow2) {
 #pragma unroll
         for (int e = 0; e < CG; ++e) {
 #pragma unroll
@@ -424,8 +442,17 @@ __global__ __launch_bounds__(256) void c1_s2_wgrad_kernel(const C1Params p) {
     }
     // one LDS image per wave; when the channel groups tile the wave each entry has a single writer and the
     // result is order-independent, otherwise (N/8 not a power of two) LDS float atomics are used
-    float* mine = sm + (threadIdx.x >> 6) * p.N * 10;
-    if (pow2) {
+    float* mine = sm + (QUAD ? (threadIdx.x >> 4) : (threadIdx.x >> 6)) * p.N * 10;
+    if (QUAD) {
+        if ((threadIdx.x & 15) >= 12) {
+#pragma unroll
+            for (int e = 0; e < CG; ++e) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) mine[(grp * CG + e) * 10 + k] = acc[e][k];
+                mine[(grp * CG + e) * 10 + 9] = accb[e];
+            }
+        }
+    } else if (pow2) {
         if ((threadIdx.x & 63) < G) {
 #pragma unroll
             for (int e = 0; e < CG; ++e) {
@@ -448,12 +475,18 @@ __global__ __launch_bounds__(256) void c1_s2_wgrad_kernel(const C1Params p) {
     for (int i = threadIdx.x; i < p.N * 9; i += 256) {
         const int n = i / 9, k = i - n * 9;
         const int o = n * 10 + k;
-        p.partial[(slab * KK + kz * 9 + k) * p.N + n] = ((sm[o] + sm[wstride + o]) + sm[2 * wstride + o]) + sm[3 * wstride + o];
+        float a = sm[o];
+#pragma unroll
+        for (int im = 1; im < NIMG; ++im) a += sm[im * wstride + o];
+        p.partial[(slab * KK + kz * 9 + k) * p.N + n] = a;
     }
     if (kz == 0)
         for (int n = threadIdx.x; n < p.N; n += 256) {
             const int o = n * 10 + 9;
-            p.partial_bias[slab * p.N + n] = ((sm[o] + sm[wstride + o]) + sm[2 * wstride + o]) + sm[3 * wstride + o];
+            float a = sm[o];
+#pragma unroll
+            for (int im = 1; im < NIMG; ++im) a += sm[im * wstride + o];
+            p.partial_bias[slab * p.N + n] = a;
         }
 }
 
@@ -728,8 +761,8 @@ int launch_c1_s2_wgrad(int dtype, const C1Params& p, hipStream_t st) {
     MI_CHECK(p.N % 8 == 0 && p.N >= 8 && p.N <= 512 && p.N / C1_WGRAD_CG <= 256, "N must be a multiple of 8, at most 512");
     MI_CHECK(p.n_y1 % 8 == 0 && p.n_y1 > 0 && (p.n_y1 >= p.N || p.y2 != nullptr), "second source missing or misaligned");
     MI_CHECK(p.nsplit == c1_wgrad_slabs(p.N, p.cd), "nsplit must come from c1_wgrad_slabs()");
-    const size_t lds = (size_t)4 * p.N * 10 * sizeof(float);
     const bool quad = p.N / C1_WGRAD_CG == 4;
+    const size_t lds = (size_t)(quad ? 16 : 4) * p.N * 10 * sizeof(float);   // one image per wave, per 16-lane row in the quad variant
     dim3 grid(p.nsplit, p.ndim == 3 ? 3 : 1);
 #define C1W_CASE(TR, Q)                                                                   \
     do {                                                                                  \
