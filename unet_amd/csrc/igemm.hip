@@ -41,6 +41,15 @@ __device__ __forceinline__ int chan_of_row(int nf, int rr) {
 // ---------------------------------------------------------------------------------
 // forward / dgrad
 // ---------------------------------------------------------------------------------
+// sum over the 16 lanes of a DPP row (all lanes receive it): two quad permutes, half mirror, mirror
+__device__ __forceinline__ float row_sum16(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));  // row_mirror
+    return v;
+}
+
 template <class TR, int CPS, int NFRAG>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     constexpr int ESZ = TR::ESZ;
@@ -266,7 +275,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         }
     }
     if (do_stats) {
-        // fixed-order reduction inside the workgroup (16-lane shuffle tree, then the four waves in
+        // fixed-order reduction inside the workgroup (16-lane DPP row sums, then the four waves in
         // order); the per-workgroup sums are added to fp64 accumulators, so the result does not
         // depend on the order in which workgroups arrive (to fp32 rounding)
         __syncthreads();
@@ -275,9 +284,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         for (int nf = 0; nf < NFRAG; ++nf)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float a = s1[nf][j], b = s2[nf][j];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+                const float a = row_sum16(s1[nf][j]), b = row_sum16(s2[nf][j]);
                 if (lr == 0) {
                     const int cl = chan_of_row<NFRAG>(nf, 4 * g + j);
                     sst[(wave * NT + cl) * 2] = a;
@@ -361,14 +368,6 @@ __global__ __launch_bounds__(256) void ksplit_finish_kernel(const IgemmParams p,
     }
 }
 
-// sum over the 16 lanes of a DPP row (lanes that share lane >> 4); lane 0 of the row adds in a fixed order
-__device__ __forceinline__ float row_sum16(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));  // row_mirror
-    return v;
-}
 
 // Same contract as igemm_kernel for 2-D tensors gathered with unit stride (sa = 1) and a 16 x 16 tile.
 // KS = 3: 3x3 taps (patch 18 x 18), KS = 1: one tap (16 x 16), KS = 2: the stride-2 scatter phases whose
