@@ -122,20 +122,48 @@ __global__ __launch_bounds__(256) void c1_s2_fwd_kernel(const C1Params p) {
     }   // row groups
     if (p.stats) {
         // fixed-order reduction over the workgroup's columns, then fp64 accumulators
-        if (pl < ppb) {
+        const int slot = (blockIdx.x + blockIdx.y) % MI_NSLOT;
+        if (G == 4) {
+            // four channel groups per column: a 16-lane row holds four columns, two DPP row shifts add them up in
+            // lanes 12..15; the 16 rows of the workgroup then meet in LDS ([2][16 rows][N])
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                sst[pl * N + grp * 8 + e] = s1[e];
-                sst[(ppb + pl) * N + grp * 8 + e] = s2[e];
+                s1[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1[e]), 0x114, 0xf, 0xf, true));
+                s1[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1[e]), 0x118, 0xf, 0xf, true));
+                s2[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s2[e]), 0x114, 0xf, 0xf, true));
+                s2[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s2[e]), 0x118, 0xf, 0xf, true));
             }
-        }
-        __syncthreads();
-        const int slot = (blockIdx.x + blockIdx.y) % MI_NSLOT;
-        for (int i = threadIdx.x; i < p.nstat * 2; i += 256) {
-            const int ch = i >> 1, k = i & 1;
-            float a = 0.f;
-            for (int r = 0; r < ppb; ++r) a += sst[(k * ppb + r) * N + ch];
-            atomicAdd(&p.stats[(((size_t)img * MI_NSLOT + slot) * p.stats_c) * 2 + i], (double)a);
+            const int row = threadIdx.x >> 4;
+            if ((threadIdx.x & 15) >= 12) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    sst[row * N + grp * 8 + e] = s1[e];
+                    sst[(16 + row) * N + grp * 8 + e] = s2[e];
+                }
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < p.nstat * 2; i += 256) {
+                const int ch = i >> 1, k = i & 1;
+                float a = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a += sst[(k * 16 + r) * N + ch];
+                atomicAdd(&p.stats[(((size_t)img * MI_NSLOT + slot) * p.stats_c) * 2 + i], (double)a);
+            }
+        } else {
+            if (pl < ppb) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    sst[pl * N + grp * 8 + e] = s1[e];
+                    sst[(ppb + pl) * N + grp * 8 + e] = s2[e];
+                }
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < p.nstat * 2; i += 256) {
+                const int ch = i >> 1, k = i & 1;
+                float a = 0.f;
+                for (int r = 0; r < ppb; ++r) a += sst[(k * ppb + r) * N + ch];
+                atomicAdd(&p.stats[(((size_t)img * MI_NSLOT + slot) * p.stats_c) * 2 + i], (double)a);
+            }
         }
     }
 }
