@@ -278,10 +278,14 @@ def test_fused_adamw_matches_torch(dev):
 
 def test_training_converges_like_oracle(dev, tmp_path):
     """A fixed number of steps on the same synthetic task: the fused trainer (bf16 and fp32), the
-    autograd path + torch AdamW and the CPU oracle end with Dice within 0.01 of one another (200 Adam steps
+    autograd path + torch AdamW and the CPU oracle end with Dice within 0.005 of one another (200 Adam steps
     amplify rounding-level differences, so the trajectories are close, not identical); the checkpoint
     written by the product loads into the oracle."""
     channels, sp, nb, steps, lr = (16, 32, 64), (64, 64), 8, 200, 5e-3
+    # the last quarter runs at a tenth of the rate (reference/train.py:91 decays with StepLR): the end point then sits
+    # in the basin instead of wherever the last large step left it, which is what makes trajectories comparable
+    def set_lr(opt_, i):
+        opt_.param_groups[0]["lr"] = lr if i < 150 else 0.1 * lr
     g = torch.Generator().manual_seed(21)
     xs = [torch.rand(nb, 1, *sp, generator=g) * 0.2 for _ in range(4)]
     ts = [disks(nb, sp, 100 + i, with_two=True) for i in range(4)]
@@ -307,6 +311,7 @@ def test_training_converges_like_oracle(dev, tmp_path):
     lo = oracle.DiceCELoss(sigmoid=True)
     o.train()
     for i in range(steps):
+        set_lr(opt, i)
         opt.zero_grad(); lo(o(xs[i % 4]), fold(ts[i % 4])).backward(); opt.step()
     d_ref = dice_of(o, False)
     assert d_ref > 0.9
@@ -317,6 +322,7 @@ def test_training_converges_like_oracle(dev, tmp_path):
         m.load_state_dict(sd0); m.to(dev).train()
         tr = unet_amd.Trainer(m, unet_amd.DiceCELoss(sigmoid=True, fold_label_two=True), unet_amd.AdamW(m.parameters(), lr=lr, model=m))
         for i in range(steps):
+            set_lr(tr.opt, i)
             tr.step(xs[i % 4].to(dev), ts[i % 4].to(dev))
         assert math.isfinite(tr.loss_sum())
         results[name] = dice_of(m, True)
@@ -330,7 +336,9 @@ def test_training_converges_like_oracle(dev, tmp_path):
     opt = torch.optim.AdamW(m.parameters(), lr=lr)
     lm = unet_amd.DiceCELoss(sigmoid=True)
     for i in range(steps):
+        set_lr(opt, i)
         opt.zero_grad(); lm(m(xs[i % 4].to(dev)), fold(ts[i % 4]).to(dev)).backward(); opt.step()
     results["autograd"] = dice_of(m, True)
+    print("dice:", d_ref, results)
     for k, v in results.items():
-        assert abs(v - d_ref) < 0.01, (k, v, d_ref)
+        assert abs(v - d_ref) < 0.005, (k, v, d_ref)

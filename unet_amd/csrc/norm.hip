@@ -62,11 +62,42 @@ __device__ __forceinline__ NormLane norm_lane(const NormParams& p) {
 // rows of the workgroup; on return part[ccv * 2*VEC + e] holds the totals of channel vector ccv (after the final
 // barrier).  Threads of one channel vector sit cv_n lanes apart: when cv_n is a power of two that fits a wave, the
 // rows inside a wave are folded with lane exchanges and only one value set per wave goes through LDS (one
-// barrier instead of one per tree level); other channel counts use a fixed-shape LDS tree.  Both orders are fixed.
+// barrier instead of one per tree level); other channel counts use a fixed-shape LDS tree.  All orders are fixed.
+template <int O>
+__device__ __forceinline__ float row_shr_add(float v) {      // v + (value of the lane O below in the 16-lane DPP row, 0 past its start)
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + O, 0xf, 0xf, true));
+}
 template <int VEC>
 __device__ __forceinline__ void sum_rows(float* s, float* part, const NormLane& l, int cv_n) {
     constexpr int W = 2 * VEC;
-    if ((cv_n & (cv_n - 1)) == 0 && cv_n <= 64 && cv_n >= 8) {     // at most three exchange steps; below that the tree is cheaper
+    if (cv_n == 1 || cv_n == 2 || cv_n == 4) {
+        // few channel vectors: the threads of one vector sit 1, 2 or 4 lanes apart inside a 16-lane DPP row; row
+        // shifts (register-to-register) fold the row into its last cv_n lanes, the 16 rows of the workgroup
+        // then meet in LDS
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            float v = s[e];
+            if (cv_n == 1) v = row_shr_add<1>(v);
+            if (cv_n <= 2) v = row_shr_add<2>(v);
+            v = row_shr_add<4>(v);
+            v = row_shr_add<8>(v);
+            s[e] = v;
+        }
+        const int lr16 = threadIdx.x & 15, row = threadIdx.x >> 4;
+        if (lr16 >= 16 - cv_n) {
+#pragma unroll
+            for (int e = 0; e < W; ++e) part[(row * cv_n + (lr16 & (cv_n - 1))) * W + e] = s[e];
+        }
+        __syncthreads();
+        const int n = cv_n * W;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            float tot = part[i];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) tot += part[r * n + i];
+            part[i] = tot;                                   // column i is touched by this thread only
+        }
+        __syncthreads();
+    } else if ((cv_n & (cv_n - 1)) == 0 && cv_n <= 64 && cv_n >= 8) {     // at most three exchange steps; below that the tree is cheaper
         for (int o = 32; o >= cv_n; o >>= 1) {
 #pragma unroll
             for (int e = 0; e < W; ++e) s[e] += __shfl_xor(s[e], o, 64);
