@@ -995,6 +995,15 @@ int run_step(mi_unet& u, Step& s, char* const* bases, int training, uint64_t see
 
 bool is_wgrad_kind(int kind) { return kind == K_WGRAD || kind == K_C1_WGRAD || kind == K_STENCIL_WGRAD; }
 
+// The fork / join events order kernels of two streams of one device and are never inspected by the host.  Every
+// kernel boundary already releases and acquires at device scope, so the events need no system-scope fence of
+// their own; without it a record costs the main chain ~3 us instead of ~5 (30 records per training step).
+// MI_EVENT_SYSTEM_FENCE=1 restores the default event behaviour.
+unsigned fork_event_flags() {
+    static const bool sys = getenv("MI_EVENT_SYSTEM_FENCE") && atoi(getenv("MI_EVENT_SYSTEM_FENCE")) != 0;
+    return hipEventDisableTiming | (sys ? 0u : (unsigned)hipEventDisableSystemFence);
+}
+
 int run_list(mi_unet& u, std::vector<Step>& list, int backward, int bucket, char* const* bases, int training, uint64_t seed,
              hipStream_t st) {
     // A second stream runs work that is off the critical chain: in the backward pass the weight gradients and
@@ -1006,7 +1015,7 @@ int run_list(mi_unet& u, std::vector<Step>& list, int backward, int bucket, char
             u.use_side = getenv("MI_NO_SIDE_STREAM") ? 0 : 1;
             if (u.use_side) {
                 if (hipStreamCreateWithFlags(&u.side, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); u.use_side = 0; }
-                else if (hipEventCreateWithFlags(&u.join_ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); u.use_side = 0; }
+                else if (hipEventCreateWithFlags(&u.join_ev, fork_event_flags()) != hipSuccess) { (void)hipGetLastError(); u.use_side = 0; }
             }
         }
         side = u.use_side == 1;
@@ -1016,7 +1025,7 @@ int run_list(mi_unet& u, std::vector<Step>& list, int backward, int bucket, char
     auto fork = [&]() -> int {      // the side stream waits for everything enqueued on the main stream so far
         if (nside >= u.side_ev.size()) {
             hipEvent_t e;
-            MI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            MI_HIP(hipEventCreateWithFlags(&e, fork_event_flags()));
             u.side_ev.push_back(e);
         }
         hipEvent_t ready = u.side_ev[nside++];
