@@ -51,36 +51,77 @@ def synthetic_batch(nb, sp, seed, device):
     return x.to(device), t.to(device)
 
 
-def cpu_baseline(budget_s=15.0, dropout=0.1):
+def host_threads():
+    """Threads the CPU baseline may use: the process's CPU share.  On a shared host os.cpu_count() reports the
+    whole machine, so the count is capped by the scheduler affinity and by OMP_NUM_THREADS when that is set."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    env = os.environ.get("OMP_NUM_THREADS", "")
+    if env.isdigit() and int(env) > 0:
+        n = min(n, int(env))
+    return max(1, n)
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(budget_s=12.0, dropout=0.0):
     """The CPU oracle (plain torch restatement of the reference path) on BASELINE.json configs[0]:
-    2-D 16-256 U-Net, fp32, batch 8 of 256x256, forward + DiceCE loss + backward + AdamW."""
+    2-D 16-256 U-Net, fp32, batch 8 of 256x256, zero_grad + forward + Dice loss + backward + AdamW,
+    dropout 0.0; 5 warm-up steps, then up to 20 timed steps with every host thread of this process's
+    CPU share, then a single-thread run (fewer steps: both legs are bounded by `budget_s`)."""
     import oracle
 
-    threads = torch.get_num_threads()
-    torch.manual_seed(0)
-    model = oracle.UNet(2, 1, 1, (16, 32, 64, 128, 256), (2, 2, 2, 2), num_res_units=2, dropout=dropout)
-    model.train()
-    loss = oracle.DiceCELoss(to_onehot_y=False, sigmoid=True)
-    opt = torch.optim.AdamW(model.parameters(), lr=5e-4)
+    threads = host_threads()
     x, t = synthetic_batch(8, (256, 256), 1234, "cpu")
     t[t == 2] = 1
 
-    def step():
-        opt.zero_grad()
-        loss(model(x), t).backward()
-        opt.step()
+    def run(nthreads, warm, steps, budget):
+        torch.set_num_threads(nthreads)
+        torch.manual_seed(0)
+        model = oracle.UNet(2, 1, 1, (16, 32, 64, 128, 256), (2, 2, 2, 2), num_res_units=2, dropout=dropout)
+        model.train()
+        loss = oracle.DiceLoss(sigmoid=True)
+        opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=1e-5)
 
-    step()  # warm-up (thread pool, allocator)
-    n, t0 = 0, time.perf_counter()
-    while True:
-        step()
-        n += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or n >= 400:
-            break
+        def step():
+            opt.zero_grad()
+            loss(model(x), t).backward()
+            opt.step()
+
+        for _ in range(warm):
+            step()
+        n, t0 = 0, time.perf_counter()
+        while n < steps:
+            step()
+            n += 1
+            if time.perf_counter() - t0 > budget:
+                break
+        return n, time.perf_counter() - t0
+
+    before = torch.get_num_threads()
+    n, el = run(threads, 5, 20, budget_s)
+    n1, el1 = run(1, 1, 5, budget_s)
+    torch.set_num_threads(before)
+    gf_step = 36.2
     return {"value": round(8 * n / el, 2), "unit": "slices/s", "cores": threads, "kind": "port",
-            "sample": f"{n} steps of batch 8 x 256x256 fp32 (fwd+loss+bwd+AdamW) in {el:.1f} s; "
-                      f"configs[0]; oracle = torch-CPU restatement of the reference path"}
+            "value_1thread": round(8 * n1 / el1, 2), "gflops": round(gf_step * n / el, 1),
+            "gflops_1thread": round(gf_step * n1 / el1, 1), "cpu_model": cpu_model(), "host_cpu_count": os.cpu_count(),
+            "dropout": dropout,
+            "sample": f"{n} steps ({threads} threads, {el:.1f} s) and {n1} steps (1 thread, {el1:.1f} s) of batch 8 x 256x256 "
+                      f"fp32, zero_grad+fwd+Dice loss+bwd+AdamW, dropout {dropout}; configs[0]; oracle = torch-CPU "
+                      f"restatement of the reference path"}
 
 
 def kernel_table(plan, nsteps):
@@ -98,8 +139,65 @@ def kernel_table(plan, nsteps):
     return rows
 
 
+def launch_ranks(n, argv):
+    """Parent of a multi-GPU run started without torchrun: starts `n` ranks of this script under
+    torch.distributed.run (one per GPU), passes rank 0's JSON line through and fails when any rank fails or the
+    line does not report `n` ranks.  The parent never touches the GPU."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    log(f"[bench] launching {n} ranks: {' '.join(cmd[1:])}")
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for ln in proc.stdout.splitlines():
+        try:
+            d = json.loads(ln)
+        except ValueError:
+            continue
+        if isinstance(d, dict) and "metric" in d:
+            line = (ln, d)
+    if proc.returncode != 0:
+        raise SystemExit(f"bench.py: the {n}-rank run failed (exit code {proc.returncode})")
+    if line is None:
+        raise SystemExit("bench.py: rank 0 printed no result line")
+    if line[1].get("n_gpus") != n:
+        raise SystemExit(f"bench.py: asked for {n} ranks, the run reports {line[1].get('n_gpus')}")
+    print(line[0], flush=True)
+
+
+def dry_run(args):
+    """Rendezvous check without a GPU: the ranks meet over gloo, sum their ranks and rank 0 prints a line of
+    the usual shape.  Used by the CPU tests of the launcher."""
+    import torch.distributed as dist
+    from unet_amd.parallel import init_from_env
+
+    rank, world, _ = init_from_env("gloo")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {world} rank(s)")
+    v = torch.tensor([float(rank)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(v)
+        dist.barrier()
+    assert float(v.item()) == world * (world - 1) / 2
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (rendezvous only)", "value": 0.0, "unit": "none", "n_gpus": world, "steps": 0,
+                          "warmup": 0, "ms_per_step": 0.0, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "none", "data": "none", "config": {"workload": "none", "parallelism": f"dp{world}"}}),
+              flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--dry-run", action="store_true", help="rendezvous of the ranks over gloo only (no GPU work): launcher test")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=10)
@@ -122,15 +220,27 @@ def main():
                     help="windows per model call in --mode infer (reference/train.py:140 passes 4; windows are independent samples, so the count changes throughput only)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus, sys.argv[1:])      # this process becomes the parent of the ranks
+        return
+    if args.dry_run:
+        dry_run(args)
+        return
+
     import unet_amd
     from unet_amd.parallel import init_from_env, broadcast_parameters
     import torch.distributed as dist
 
     rank, world, local = init_from_env()
     if world != args.gpus:
-        log(f"[bench] note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: start it as `python bench.py --gpus N` "
+                         f"or under torch.distributed.run with --nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU: the HIP path has no CPU fallback")
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local} but only {torch.cuda.device_count()} are visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -350,7 +460,7 @@ def main():
         out["roofline"] = roof
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(dropout=args.dropout)
+        out["cpu_baseline"] = cpu_baseline()
 
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""python scripts/unet_test.py --checkpoint_name unet_task03_liver_real_2D.pth --images_dir ... --labels_dir ..."""
+"""python scripts/unet_test.py --checkpoint_name unet_task03_liver_box_pseudolabels_2D.pth --images_dir ... --labels_dir ..."""
 import os
 import sys
 

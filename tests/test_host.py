@@ -129,4 +129,36 @@ def test_volume_grouping_and_checkpoint_names():
     names = ["liver_3_10.nii.gz", "liver_3_11.nii.gz", "liver_7_2.nii.gz", "liver_7_3.nii.gz"]
     d = unet_amd.per_volume_dice(names, [0.5, 1.0, float("nan"), 0.8])
     assert d == {"liver_3": 0.75, "liver_7": 0.8}
-    assert unet_amd.checkpoint_name("Task03_Liver", "pseudo", "2d", "box") == "unet_task03_liver_box_pseudolabels_2D.pth"
+
+
+def test_checkpoint_names_follow_the_reference_branch_for_branch():
+    """reference/utils/utils.py:172-187 with the flags of reference/config.py; expected strings worked out by hand
+    from that function."""
+    cn = unet_amd.checkpoint_name
+    table = [
+        (dict(organ="Task03_Liver"), "unet_task03_liver_all_2D.pth"),
+        (dict(organ="Task03_Liver", train_data="all", use_pseudo_labels=True, sam_prompt="box"),
+         "unet_task03_liver_box_pseudolabels_2D.pth"),                       # the README's example file (README.md:28)
+        (dict(organ="Task08_HepaticVessel", use_pseudo_labels=True, sam_prompt="box_and_then_point"),
+         "unet_task08_hepaticvessel_box_and_then_point_pseudolabels_2D.pth"),
+        (dict(organ="Task03_Liver", train_data="n_random", n_train_samples=1000), "unet_task03_liver_1000_random_2D.pth"),
+        (dict(organ="Task09_Spleen", train_data="n_worst", n_train_samples=250), "unet_task09_spleen_250_worst_2D.pth"),
+        # a subset run ignores the pseudo-label flag in the name (the reference tests TRAIN_DATA first)
+        (dict(organ="Task03_Liver", train_data="n_worst", use_pseudo_labels=True), "unet_task03_liver_1000_worst_2D.pth"),
+        (dict(organ="Task03_Liver", img_format="3d"), "unet_task03_liver_3D.pth"),
+        (dict(organ="Task03_Liver", img_format="3d", train_data="n_random", use_pseudo_labels=True), "unet_task03_liver_3D.pth"),
+    ]
+    for kw, want in table:
+        assert cn(**kw) == want, (kw, cn(**kw))
+    with pytest.raises(ValueError):
+        cn("Task03_Liver", img_format="4d")
+
+
+def test_unet_config_is_read_off_a_state_dict():
+    from unet_amd.utils import unet_config_from_state_dict
+    for dims, ch, ru in [(2, (32, 64, 128, 256, 512), 2), (2, (16, 32, 64), 1), (3, (16, 32, 64, 128, 256), 2)]:
+        o = oracle.UNet(dims, 1, 1, ch, (2,) * (len(ch) - 1), num_res_units=ru)
+        cfg = unet_config_from_state_dict(o.state_dict())
+        assert cfg == dict(spatial_dims=dims, channels=ch, strides=(2,) * (len(ch) - 1), num_res_units=ru)
+    with pytest.raises(ValueError):
+        unet_config_from_state_dict({"weight": torch.zeros(1)})

@@ -16,8 +16,8 @@ def test_run_test_on_nifti_directory(dev, tmp_path):
     torch.manual_seed(11)
     channels = (16, 32, 64)
     model = unet_amd.UNet(2, 1, 1, channels, (2, 2), num_res_units=2, compute_dtype=torch.float32)
-    ck = unet_amd.save_checkpoint(model, str(tmp_path / "models" / unet_amd.checkpoint_name("Task03_Liver")))
-    assert ck.endswith("unet_task03_liver_real_2D.pth")
+    ck = unet_amd.save_checkpoint(model, str(tmp_path / "models" / unet_amd.checkpoint_name("Task03_Liver", use_pseudo_labels=True, sam_prompt="box")))
+    assert ck.endswith("unet_task03_liver_box_pseudolabels_2D.pth")       # the file reference/README.md:28 tests
     rng = np.random.RandomState(1)
     (tmp_path / "img").mkdir(); (tmp_path / "lbl").mkdir()
     names = ["liver_2_10", "liver_2_9", "liver_15_0", "liver_15_1", "liver_15_2"]
@@ -30,8 +30,8 @@ def test_run_test_on_nifti_directory(dev, tmp_path):
         write_nifti(tmp_path / "lbl" / f"{n}.nii.gz", lab[i].astype(np.float32))
     items = list_slices(str(tmp_path / "img"), str(tmp_path / "lbl"))
     assert [n for n, _, _ in items] == ["liver_15_0", "liver_15_1", "liver_15_2", "liver_2_9", "liver_2_10"]
-    table, summary = run_test(ck, str(tmp_path / "img"), str(tmp_path / "lbl"), channels, (2, 2), roi=32,
-                              compute_dtype=torch.float32)
+    # channels and residual units are read from the checkpoint
+    table, summary = run_test(ck, str(tmp_path / "img"), str(tmp_path / "lbl"), roi=32, compute_dtype=torch.float32)
     # the same evaluation straight from the arrays
     order = [names.index(n) for n, _, _ in items]
     x = np.clip((np.stack(raws)[order] + 175.0) / 425.0, 0, 1).astype(np.float32)

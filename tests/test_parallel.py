@@ -116,3 +116,31 @@ def test_single_process_is_a_no_op():
     ar.launch(0); ar.launch(1); ar.wait()
     assert torch.equal(g, torch.arange(10, dtype=torch.float32))
     assert init_from_env() == (0, 1, 0) or dist.is_initialized()
+
+
+def _run_bench(args, env_extra=None):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, env=env,
+                          timeout=240)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without torchrun's environment starts two ranks itself; rank 0's line reports
+    the size of the process group."""
+    import json
+    r = _run_bench(["--gpus", "2", "--dry-run"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    assert lines[0]["n_gpus"] == 2 and lines[0]["config"]["parallelism"] == "dp2"
+
+
+def test_bench_refuses_a_world_size_that_differs_from_gpus():
+    r = _run_bench(["--gpus", "2", "--dry-run"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0
+    assert "--gpus 2" in (r.stderr + r.stdout)

@@ -18,7 +18,7 @@ import torch
 from .evaluator import VolumeEvaluator
 from .nets import UNet
 from .nifti import read_nifti
-from .utils import volume_id
+from .utils import unet_config_from_state_dict, volume_id
 
 
 def list_slices(images_dir: str, labels_dir: str) -> List[Tuple[str, str, str]]:
@@ -52,11 +52,18 @@ def load_slices(items: Sequence[Tuple[str, str, str]], a_min=-175.0, a_max=250.0
     return X, Y, [n for n, _, _ in items]
 
 
-def run_test(checkpoint_path: str, images_dir: str, labels_dir: str, channels=(16, 32, 64, 128, 256), strides=(2, 2, 2, 2),
-             num_res_units: int = 2, roi: int = 256, sw_batch_size: int = 4, compute_dtype=torch.bfloat16, device="cuda"):
-    """Returns (per_volume {volume: dice}, summary {average, max, min, mean_slice_dice})."""
-    model = UNet(2, 1, 1, tuple(channels), tuple(strides), num_res_units=num_res_units, compute_dtype=compute_dtype)
+def run_test(checkpoint_path: str, images_dir: str, labels_dir: str, channels=None, strides=None,
+             num_res_units=None, roi: int = 256, sw_batch_size: int = 4, compute_dtype=torch.bfloat16, device="cuda"):
+    """Returns (per_volume {volume: dice}, summary {average, max, min, mean_slice_dice}).  ``channels`` /
+    ``num_res_units`` default to what the checkpoint's tensor shapes say (the reference trains 32-512 channels,
+    reference/train.py:82; the benchmark configurations 16-256)."""
     state = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
+    cfg = unet_config_from_state_dict(state)
+    if cfg["spatial_dims"] != 2:
+        raise ValueError("the legacy test run evaluates 2-D slices; this checkpoint holds a 3-D network")
+    channels = tuple(channels) if channels else cfg["channels"]
+    strides = tuple(strides) if strides else (2,) * (len(channels) - 1)
+    model = UNet(2, 1, 1, channels, strides, num_res_units=num_res_units or cfg["num_res_units"], compute_dtype=compute_dtype)
     model.load_state_dict(state)
     model.to(device).eval()
     X, Y, names = load_slices(list_slices(images_dir, labels_dir), device=device)
@@ -69,18 +76,18 @@ def run_test(checkpoint_path: str, images_dir: str, labels_dir: str, channels=(1
 
 def main(argv=None):
     ap = argparse.ArgumentParser(description="Evaluate a U-Net checkpoint on a directory of 2-D NIfTI slices")
-    ap.add_argument("--checkpoint_name", required=True, help="file name of the .pth state dict, e.g. unet_task03_liver_real_2D.pth")
+    ap.add_argument("--checkpoint_name", required=True, help="file name of the .pth state dict, e.g. unet_task03_liver_box_pseudolabels_2D.pth")
     ap.add_argument("--model_dir", default="output/unet/pretrained")
     ap.add_argument("--images_dir", required=True)
     ap.add_argument("--labels_dir", required=True)
-    ap.add_argument("--channels", default="16,32,64,128,256")
+    ap.add_argument("--channels", default="", help="comma-separated; default: read from the checkpoint")
     ap.add_argument("--roi", type=int, default=256)
     ap.add_argument("--sw_batch_size", type=int, default=4)
     ap.add_argument("--dtype", default="bf16", choices=("bf16", "fp32"))
     a = ap.parse_args(argv)
-    channels = tuple(int(c) for c in a.channels.split(","))
+    channels = tuple(int(c) for c in a.channels.split(",")) if a.channels else None
     table, summary = run_test(os.path.join(a.model_dir, a.checkpoint_name), a.images_dir, a.labels_dir, channels,
-                              (2,) * (len(channels) - 1), roi=a.roi, sw_batch_size=a.sw_batch_size,
+                              None, roi=a.roi, sw_batch_size=a.sw_batch_size,
                               compute_dtype=torch.bfloat16 if a.dtype == "bf16" else torch.float32)
     for v, d in sorted(table.items()):
         print(f"{v:24s} {d:.4f}")

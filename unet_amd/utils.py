@@ -29,14 +29,48 @@ def set_determinism(seed=None, model=None) -> None:
         model.seed_dropout(seed)
 
 
-def checkpoint_name(organ: str, train_data: str = "real", img_format: str = "2d", sam_prompt: str = "box",
-                    n_samples=None) -> str:
-    """Legacy file name ``unet_{organ}_{traindata}_{2D|3D}.pth`` (reference/utils/utils.py:172-187)."""
-    organ_key = organ.split("_")[1].lower() if "_" in organ else organ.lower()
-    task = organ.split("_")[0].lower() if "_" in organ else "task"
-    tag = f"{sam_prompt}_pseudolabels" if train_data != "real" else "real"
-    n = f"_{n_samples}" if n_samples else ""
-    return f"unet_{task}_{organ_key}_{tag}{n}_{img_format.upper()}.pth"
+TRAIN_DATA_LIST = ("all", "n_random", "n_worst")     # reference/config.py:15
+
+
+def checkpoint_name(organ: str, train_data: str = "all", img_format: str = "2d", use_pseudo_labels: bool = False,
+                    sam_prompt: str = "box", n_train_samples: int = 1000) -> str:
+    """File name of ``saveCheckpoint`` (reference/utils/utils.py:172-187), from the legacy flags of
+    reference/config.py: ``ORGAN`` (:12), ``TRAIN_DATA`` (:15-16), ``N_TRAIN_SAMPLES`` (:17), ``USE_PSEUDO_LABELS``
+    (:22), ``SAM_PROMPT`` (:26), ``IMG_FORMAT`` (:5).
+
+    2-D: ``unet_{organ.lower()}_{tag}_2D.pth`` with tag ``{N}_{random|worst}`` when ``train_data`` is a subset
+    (the pseudo-label flag is not looked at in that branch), else ``{prompt}_pseudolabels`` or ``all``.
+    3-D: ``unet_{organ.lower()}_3D.pth``."""
+    if img_format == "3d":
+        return f"unet_{organ.lower()}_3D.pth"
+    if img_format != "2d":
+        raise ValueError(f"img_format must be '2d' or '3d', got {img_format!r}")
+    if train_data != "all":
+        tag = f"{n_train_samples}_{train_data.split('_')[1]}"
+    elif use_pseudo_labels:
+        tag = f"{sam_prompt}_pseudolabels"
+    else:
+        tag = f"{train_data}"
+    return f"unet_{organ.lower()}_{tag}_2D.pth"
+
+
+def unet_config_from_state_dict(state) -> dict:
+    """Constructor arguments (spatial_dims, channels, strides, num_res_units) read off the tensor shapes of a
+    MONAI-layout ``state_dict``: the reference trains 32-512 channels (reference/train.py:82), the benchmark
+    configurations 16-256, and either file must load without the caller knowing which it is."""
+    channels, prefix = [], "model"
+    while f"{prefix}.0.conv.unit0.conv.weight" in state:
+        channels.append(int(state[f"{prefix}.0.conv.unit0.conv.weight"].shape[0]))
+        prefix += ".1.submodule"
+    bottom = f"{prefix}.conv.unit0.conv.weight"
+    if not channels or bottom not in state:
+        raise ValueError("not a residual U-Net state_dict in MONAI's key layout")
+    channels.append(int(state[bottom].shape[0]))
+    units = 0
+    while f"model.0.conv.unit{units}.conv.weight" in state:
+        units += 1
+    return dict(spatial_dims=state[bottom].dim() - 2, channels=tuple(channels), strides=(2,) * (len(channels) - 1),
+                num_res_units=units)
 
 
 def save_checkpoint(model: torch.nn.Module, path: str) -> str:
