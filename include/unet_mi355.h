@@ -98,6 +98,20 @@ int mi_unet_step_info(const mi_unet* u, int backward, int i, mi_step_info* info)
 /* debug aid: workspace offset of the tensor step i writes (-1: outside the workspace) */
 int64_t mi_unet_step_output_offset(const mi_unet* u, int backward, int i);
 int64_t mi_unet_step_aux_offset(const mi_unet* u, int backward, int i);   /* statistics block of a norm step */
+/* Parity-test aid: where the k-th InstanceNorm + Dropout + PReLU block of the forward pass (in execution order =
+ * the order in which MONAI's ADN modules run, reference/train.py:115) keeps its input in the workspace after
+ * mi_unet_forward: the raw convolution output and the fp64 statistic slots [nb][8][c][2] {sum, sum of squares}.
+ * From these a test recomputes which side of the PReLU kink every activation took. */
+typedef struct mi_norm_info {
+    int64_t raw_offset;        /* workspace byte offset of the raw conv output, channels-last [nb][npix][pitch] */
+    int32_t pitch, coff, c;
+    int32_t dtype;             /* element type of the raw tensor: 0 fp32, 1 bf16 */
+    int64_t npix;              /* pixels per image at this level */
+    int64_t stats_offset;      /* workspace byte offset of the statistic slots */
+    uint32_t layer;            /* layer id that keys this block's dropout stream */
+} mi_norm_info;
+int mi_unet_num_norms(const mi_unet* u);
+int mi_unet_norm_info(const mi_unet* u, int k, mi_norm_info* info);
 
 /* ------------------------------------------------------------------------------------------
  * Loss / metric.  Replaces DiceCELoss(to_onehot_y=False, sigmoid=True)(outputs, labels) and its

@@ -9,7 +9,10 @@ HIP path and the oracle against regressions of either side.
 Files (each < 1 MB):
   unet2d_small.npz   2-D (16,32,64) network: every parameter, input, labels, logits, DiceCE loss, every gradient
   unet2d_16_256.npz  2-D (16,32,64,128,256) network (reference/train.py:78-86) built from seed 0: input, labels,
-                     logits, loss, per-tensor gradient sums / norms / first elements, and a checksum of the weights
+                     logits, loss, a checksum of the weights, and for every gradient tensor its sum, norm, maximum and
+                     up to 256 elements at fixed pseudo-random positions (fp64 oracle).  The input is the first of a
+                     seed sequence for which no PReLU input of the fp64 oracle lies within 2e-5 of zero, so an fp32
+                     implementation takes the same side of every kink and single gradient elements can be compared
   unet3d_small.npz   3-D (16,32,64) network from seed 0: same content as the 16-256 file
   closed_forms.npz   loss / metric / sliding-window cases with analytically known answers
 """
@@ -63,14 +66,47 @@ def grad_summary(model):
     return np.array(names), np.array(sums), np.array(norms), np.stack(firsts)
 
 
+KINK_MARGIN = 2e-5      # smallest |PReLU input| accepted for a seed-built fixture (normalised units)
+SAMPLES = 256           # gradient elements stored per tensor
+
+
+def sample_index(i, numel):
+    """Positions of the stored elements of gradient tensor number i (shared with the test through this rule:
+    numpy RandomState(1000 + i), a sorted draw without replacement)."""
+    if numel <= SAMPLES:
+        return np.arange(numel)
+    return np.sort(np.random.RandomState(1000 + i).choice(numel, SAMPLES, replace=False))
+
+
 def seeded(dims, channels, shape, fname):
+    from oracle.inject import record_preactivations
+
     torch.manual_seed(0)
     m = oracle.UNet(dims, 1, 1, channels, (2,) * (len(channels) - 1), num_res_units=2, dropout=0.0)
-    x, t = inputs(shape, 1)
-    y, loss = run(m, x, t)
-    names, sums, norms, firsts = grad_summary(m)
-    np.savez_compressed(os.path.join(OUT, fname), x=x.numpy(), t=t.numpy(), logits=y.numpy(), loss=np.float64(loss),
-                        grad_names=names, grad_sums=sums, grad_norms=norms, grad_firsts=firsts,
+    m.eval()
+    m64 = oracle.UNet(dims, 1, 1, channels, (2,) * (len(channels) - 1), num_res_units=2, dropout=0.0).double()
+    m64.load_state_dict({k: v.double() for k, v in m.state_dict().items()})
+    m64.eval()
+    for seed in range(1, 2000):
+        x, t = inputs(shape, seed)
+        margin = min(float(d.abs().min()) for d in record_preactivations(m64, x.double()))
+        if margin > KINK_MARGIN:
+            break
+    else:
+        raise RuntimeError("no kink-safe input found")
+    y, loss = run(m64, x.double(), t.double())
+    names, sums, norms, firsts = grad_summary(m64)
+    samples = np.zeros((len(names), SAMPLES))
+    maxima = np.zeros(len(names))
+    for i, (_, p) in enumerate(m64.named_parameters()):
+        g = p.grad.detach().flatten().numpy()
+        idx = sample_index(i, g.size)
+        samples[i, :idx.size] = g[idx]
+        maxima[i] = np.abs(g).max()
+    print(f"{fname}: input seed {seed}, kink margin {margin:.3e}")
+    np.savez_compressed(os.path.join(OUT, fname), x=x.numpy(), t=t.numpy(), logits=y.float().numpy(), loss=np.float64(loss),
+                        grad_names=names, grad_sums=sums, grad_norms=norms, grad_firsts=firsts, grad_samples=samples,
+                        grad_max=maxima, input_seed=np.int64(seed), kink_margin=np.float64(margin),
                         weight_checksum=np.float64(weight_checksum(m)), channels=np.array(channels), dims=np.int64(dims))
 
 

@@ -3,10 +3,14 @@ one visible GPU) train on the halves of a batch with the bucketed, overlapped gr
 parameters must follow a single-process run on the whole batch.
 
 Not collected by pytest (the file name does not start with test_): run it by hand with
-``python -m pytest tests/manual_dp_gpu.py``.  It passes, but about one run in six both ranks stay inside
-gloo's all-reduce on device tensors when two processes share one GPU (seen with and without the
-side-stream weight gradients), and a hung test would hide every test after it.  The same logic runs on
-every round in tests/test_parallel.py with CPU tensors."""
+``python -m pytest tests/manual_dp_gpu.py -s``.  Two processes time-share the one GPU and gloo completes its
+collectives on the host, so this is a correctness rehearsal, not a model of the RCCL run.  An earlier version
+issued one blocking all-reduce per bucket between the bucket launches of the backward pass and armed a 30 s
+watchdog from process start; about one run in six ended in that watchdog with both ranks inside an
+all-reduce.  The collectives are now asynchronous until ``BucketedAllReduce.wait`` (the host no longer waits
+for the peer in the middle of the enqueue) and the watchdog allows 150 s with time stamps printed per step.
+The same logic runs on every round in tests/test_parallel.py with CPU tensors, and the bucket / stream / event
+path runs on the GPU over RCCL in tests/test_dp_rccl_gpu.py."""
 import os
 import socket
 
@@ -33,8 +37,12 @@ def _train(x, t, steps, group_ready):
     opt = unet_amd.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-5, model=m)
     tr = unet_amd.Trainer(m, unet_amd.DiceCELoss(sigmoid=True), opt)
     grads = None
+    import time
+    t0 = time.time()
     for i in range(steps):
         tr.step(x.to(dev), t.to(dev))
+        torch.cuda.synchronize()
+        print(f"[rank {tr.rank}/{tr.world}] step {i} done at +{time.time() - t0:.2f} s", flush=True)
         if i == 0:
             torch.cuda.synchronize()
             grads = (tr._grad / tr.world).cpu().clone()       # the gradient the optimizer consumed in step 1
@@ -47,7 +55,7 @@ def _worker(rank, world, port, out):
     from unet_amd.parallel import init_from_env, shard_batch
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import faulthandler
-    faulthandler.dump_traceback_later(30, exit=True)      # a stuck collective must not outlive the test
+    faulthandler.dump_traceback_later(150, exit=True)      # a stuck collective must not outlive the test
     try:
         init_from_env("gloo")
         torch.cuda.set_device(0)

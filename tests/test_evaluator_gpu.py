@@ -72,6 +72,8 @@ def test_window_grouping_keeps_results_and_respects_other_predictors(dev, monkey
     m.train()
     sizes.clear()
     from unet_amd.inferers import _windows_per_call
-    assert _windows_per_call(m, 4, nwin, 32 * 32) == 4           # dropout masks depend on the position in the batch
+    assert _windows_per_call(m, 4, nwin, 32 * 32) == (4, False)  # dropout masks depend on the position in the batch
     m.eval()
-    assert _windows_per_call(m, 4, nwin, 32 * 32) == min(nwin, 288)
+    assert _windows_per_call(m, 4, nwin, 32 * 32) == (32, True)  # 27 windows: one padded group of the next power of two
+    assert _windows_per_call(m, 4, 1000, 32 * 32) == (288, True)
+    assert _windows_per_call(m, 4, 3, 32 * 32) == (4, True)

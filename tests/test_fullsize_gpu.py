@@ -70,6 +70,34 @@ def test_window_as_large_as_the_image_is_the_forward_pass(dev):
     assert torch.equal(a, b)
 
 
+def test_nine_window_sliding_inference_full_size(dev):
+    """roi 256 on 512 x 512 (reference/train.py:140 with the legacy crop size; BASELINE.json configs[4]): 3 x 3
+    windows per slice at starts 0, 192, 256.  Properties that hold for any predictor, then equality with the
+    per-window forward passes blended by hand."""
+    x, _ = _batch(4, 512, dev, seed=11)
+    starts = unet_amd.window_starts((512, 512), (256, 256), 0.25)
+    assert starts == [(a, b) for a in (0, 192, 256) for b in (0, 192, 256)]
+    # identity predictor: overlap-averaging copies of the same pixels gives the image back
+    assert torch.equal(unet_amd.sliding_window_inference(x, (256, 256), 4, lambda w: w), x)
+    # constant predictor: every pixel is an average of equal constants
+    out = unet_amd.sliding_window_inference(x, (256, 256), 4, lambda w: torch.full_like(w, 3.25))
+    assert torch.equal(out, torch.full_like(x, 3.25))
+    # per-window forward of the U-Net (one window per call), accumulated and divided by the cover count in torch
+    m = _model(torch.bfloat16, dev).eval()
+    with torch.no_grad():
+        got = unet_amd.sliding_window_inference(x, (256, 256), 4, m)
+        acc = torch.zeros_like(x, dtype=torch.float64)
+        cnt = torch.zeros_like(x, dtype=torch.float64)
+        for (sy, sx) in starts:
+            for b in range(x.shape[0]):
+                y = m(x[b:b + 1, :, sy:sy + 256, sx:sx + 256].contiguous())
+                acc[b:b + 1, :, sy:sy + 256, sx:sx + 256] += y.double()
+                cnt[b:b + 1, :, sy:sy + 256, sx:sx + 256] += 1
+    assert float(cnt.min()) == 1 and float(cnt.max()) == 9
+    ref = (acc / cnt).float()
+    assert float((got - ref).abs().max()) <= 2e-6 * float(ref.abs().max())      # same window outputs; fp32 vs fp64 averaging
+
+
 def test_directional_derivative_matches_gradient_fp32(dev):
     m = _model(torch.float32, dev).eval()            # eval: no dropout; norm statistics are per sample anyway
     x, t = _batch(2, 256, dev)

@@ -50,7 +50,23 @@ def test_seed_built_network_matches_golden(dev, fname):
     assert np.abs(y.detach().cpu().numpy() - ref).max() < 1e-4 * np.abs(ref).max()
     assert abs(float(loss) - float(f["loss"])) < 1e-5
     assert [n for n, _ in m.named_parameters()] == list(f["grad_names"])
-    norms = np.array([float(p.grad.double().norm()) for p in m.parameters()])
+    # Element-wise: up to 256 elements of every gradient tensor at the fixture's fixed positions, 1e-4 of the
+    # tensor's largest element.  The fixture's input keeps every PReLU input of the fp64 oracle at least 2e-5 from
+    # zero (stored as kink_margin), so both sides take the same branch everywhere and no element is excused.
+    assert float(f["kink_margin"]) > 2e-5
+    from oracle.make_golden import sample_index
     gnorm = np.sqrt((f["grad_norms"] ** 2).sum())
-    # PReLU slopes are 0.25 here: a rare sign flip at the kink moves single elements, norms stay within 1e-3
-    assert np.abs(norms - f["grad_norms"]).max() < 1e-3 * gnorm
+    names = {n for n, _ in m.named_parameters()}
+    worst = 0.0
+    for i, (n, p) in enumerate(m.named_parameters()):
+        gm = p.grad.double().flatten().cpu().numpy()
+        idx = sample_index(i, gm.size)
+        ref_s = f["grad_samples"][i, :idx.size]
+        noise = n.endswith("conv.bias") and n.replace("conv.bias", "adn.A.weight") in names   # bias in front of a norm: true gradient 0
+        scale = 1e-2 * gnorm if noise else float(f["grad_max"][i])
+        err = np.abs(gm[idx] - ref_s).max() / max(scale, 1e-30)
+        worst = max(worst, err)
+        assert err < 1e-4, (n, err)
+        if not noise:
+            assert abs(np.linalg.norm(gm) - f["grad_norms"][i]) < 1e-4 * max(f["grad_norms"][i], 1e-3 * gnorm), n
+    print(f"{fname}: worst sampled gradient element error {worst:.2e} of the tensor maximum")

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 import oracle
-from oracle.make_golden import grad_summary, inputs, run, weight_checksum
+from oracle.make_golden import KINK_MARGIN, grad_summary, inputs, run, sample_index, weight_checksum
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -113,14 +113,29 @@ def test_oracle_reproduces_seed_built_golden(fname, shape):
     torch.manual_seed(0)
     m = oracle.UNet(dims, 1, 1, channels, (2,) * (len(channels) - 1), num_res_units=2, dropout=0.0)
     assert abs(weight_checksum(m) - float(f["weight_checksum"])) < 1e-9, "torch RNG stream or construction order changed"
-    x, t = inputs(shape, 1)
+    x, t = inputs(shape, int(f["input_seed"]))
     assert np.array_equal(x.numpy(), f["x"]) and np.array_equal(t.numpy(), f["t"])
-    y, loss = run(m, x, t)
-    assert np.allclose(y.numpy(), f["logits"], rtol=0, atol=1e-5 * np.abs(f["logits"]).max())
-    assert abs(loss - float(f["loss"])) < 1e-6
-    names, sums, norms, firsts = grad_summary(m)
+    # the fixture was written by the fp64 oracle on an input that keeps every PReLU input away from 0
+    m64 = oracle.UNet(dims, 1, 1, channels, (2,) * (len(channels) - 1), num_res_units=2, dropout=0.0).double()
+    m64.load_state_dict({k: v.double() for k, v in m.state_dict().items()})
+    m64.eval()
+    from oracle.inject import record_preactivations
+    margin = min(float(d.abs().min()) for d in record_preactivations(m64, x.double()))
+    assert margin > KINK_MARGIN and abs(margin - float(f["kink_margin"])) < 1e-9
+    y, loss = run(m64, x.double(), t.double())
+    assert np.allclose(y.numpy(), f["logits"], rtol=0, atol=1e-6 * np.abs(f["logits"]).max())
+    assert abs(loss - float(f["loss"])) < 1e-9
+    names, sums, norms, firsts = grad_summary(m64)
     assert list(names) == list(f["grad_names"])
-    assert np.allclose(norms, f["grad_norms"], rtol=1e-4, atol=1e-7)
+    assert np.allclose(norms, f["grad_norms"], rtol=1e-9, atol=1e-12)
+    for i, (_, p) in enumerate(m64.named_parameters()):
+        g = p.grad.flatten().numpy()
+        idx = sample_index(i, g.size)
+        assert np.allclose(g[idx], f["grad_samples"][i, :idx.size], rtol=1e-9, atol=1e-12)
+    # the fp32 oracle (what the CPU baseline and the other parity tests run) agrees with it
+    y32, loss32 = run(m, x, t)
+    assert np.allclose(y32.numpy(), f["logits"], rtol=0, atol=1e-5 * np.abs(f["logits"]).max())
+    assert abs(loss32 - float(f["loss"])) < 1e-6
 
 
 def test_oracle_reproduces_stored_weight_golden():

@@ -1,0 +1,134 @@
+"""Lifetime and resource behaviour of the engine on the GPU: workspaces that come and go, a bounded plan cache
+under sliding-window inference over many image sizes, finite parameter buffers on the autograd path, and the
+optimizer's checkpoint format."""
+import gc
+
+import pytest
+import torch
+
+import unet_amd
+from test_unet_gpu import disks
+
+pytestmark = pytest.mark.gpu
+
+
+def _step(plan, flat, x, dlog, ws, seed=5):
+    logits = torch.empty_like(x)
+    g = torch.zeros_like(flat)
+    plan.forward(flat, x, logits, ws, True, seed)
+    plan.backward(flat, x, dlog, g, ws, True, seed)
+    torch.cuda.synchronize()
+    return logits.clone(), g.clone()
+
+
+def test_a_recycled_workspace_block_needs_no_preparation(dev):
+    """The engine keeps nothing in a workspace between calls (descriptor tables travel as kernel arguments): a
+    block that was freed, overwritten by other tensors and handed out again at the same address works at once."""
+    torch.manual_seed(2)
+    m = unet_amd.UNet(2, 1, 1, (16, 32, 64), (2, 2), num_res_units=2, dropout=0.1, compute_dtype=torch.bfloat16).to(dev).train()
+    x = torch.rand(2, 1, 64, 64, device=dev)
+    dlog = torch.randn(2, 1, 64, 64, device=dev) * 1e-3
+    plan = m._plan_for(x, True)
+    flat = m._ensure_flat(dev)
+    ws = torch.empty(plan.workspace_bytes, dtype=torch.uint8, device=dev)
+    addr = ws.data_ptr()
+    y0, g0 = _step(plan, flat, x, dlog, ws)
+    del ws
+    junk = torch.full((plan.workspace_bytes // 4,), float("nan"), dtype=torch.float32, device=dev)   # scribble over the block
+    same_block = junk.data_ptr() == addr
+    del junk
+    ws2 = torch.empty(plan.workspace_bytes, dtype=torch.uint8, device=dev)
+    y1, g1 = _step(plan, flat, x, dlog, ws2)
+    assert torch.equal(y0, y1) and torch.equal(g0, g1)
+    # and a second workspace at another address, with the first still alive, gives the same bits as well
+    ws3 = torch.empty(plan.workspace_bytes, dtype=torch.uint8, device=dev)
+    assert ws3.data_ptr() != ws2.data_ptr()
+    y2, g2 = _step(plan, flat, x, dlog, ws3)
+    assert torch.equal(y0, y2) and torch.equal(g0, g2)
+    print("recycled block had the same address:", same_block)
+
+
+def test_sliding_window_over_many_image_sizes_keeps_memory_bounded(dev):
+    torch.manual_seed(3)
+    m = unet_amd.UNet(2, 1, 1, (16, 32, 64), (2, 2), num_res_units=2, compute_dtype=torch.bfloat16).to(dev).eval()
+    sizes = [(96 + 8 * i, 160 - 8 * (i % 7)) for i in range(20)] + [(64, 64), (70, 50), (333, 97)]
+    peak = 0
+    with torch.no_grad():
+        for k, (h, w) in enumerate(sizes):
+            x = torch.rand(1 + k % 3, 1, h, w, device=dev)
+            y = unet_amd.sliding_window_inference(x, (64, 64), 4, m)
+            assert y.shape == x.shape and bool(torch.isfinite(y).all())
+            del x, y
+            if k == 4:
+                gc.collect(); torch.cuda.synchronize()
+                base = torch.cuda.memory_allocated(dev)
+            if k > 4:
+                gc.collect(); torch.cuda.synchronize()
+                peak = max(peak, torch.cuda.memory_allocated(dev))
+    assert len(m._plans) <= m.MAX_PLANS
+    batch_sizes = sorted({k[0] for k in m._plans})
+    assert all(b & (b - 1) == 0 or b == 288 for b in batch_sizes), batch_sizes      # powers of two (or the maximum) only
+    assert peak <= 2 * base + (64 << 20), (base, peak)
+
+
+def test_autograd_path_keeps_the_flat_buffers_finite(dev):
+    torch.manual_seed(4)
+    m = unet_amd.UNet(2, 1, 1, (16, 32, 64), (2, 2), num_res_units=2, compute_dtype=torch.float32).to(dev).train()
+    opt = unet_amd.AdamW(m.parameters(), lr=1e-3, model=m)
+    loss = unet_amd.DiceCELoss(sigmoid=True)
+    x = torch.rand(2, 1, 32, 32, device=dev)
+    t = disks(2, (32, 32), 3).to(dev)
+    poison = torch.full((1 << 22,), float("nan"), device=dev)      # make stale allocator blocks hold NaN
+    del poison
+    for _ in range(3):
+        opt.zero_grad()
+        loss(m(x), t).backward()
+        assert bool(torch.isfinite(m._last_grad_flat).all())
+        opt.step()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(m.flat_parameters()).all())
+    assert bool(torch.isfinite(opt._m).all()) and bool(torch.isfinite(opt._v).all())
+
+
+def test_optimizer_state_round_trips_in_torch_format(dev):
+    def make():
+        torch.manual_seed(6)
+        m = unet_amd.UNet(2, 1, 1, (16, 32), (2,), num_res_units=2, compute_dtype=torch.float32).to(dev).train()
+        return m, unet_amd.AdamW(m.parameters(), lr=2e-3, weight_decay=1e-2, model=m)
+
+    loss = unet_amd.DiceCELoss(sigmoid=True)
+    x = torch.rand(2, 1, 32, 32, device=dev)
+    t = disks(2, (32, 32), 8).to(dev)
+
+    def step(m, opt):
+        opt.zero_grad()
+        loss(m(x), t).backward()
+        opt.step()
+
+    m1, o1 = make()
+    for _ in range(3):
+        step(m1, o1)
+    sd_model = {k: v.clone() for k, v in m1.state_dict().items()}
+    sd_opt = o1.state_dict()
+    assert len(sd_opt["state"]) == 21 and float(sd_opt["state"][0]["step"]) == 3.0
+    step(m1, o1)
+    # resume in a fresh model / optimizer
+    m2, o2 = make()
+    m2.load_state_dict(sd_model)
+    o2.load_state_dict(sd_opt)
+    step(m2, o2)
+    torch.cuda.synchronize()
+    assert torch.equal(m1.flat_parameters(), m2.flat_parameters())
+    # the same file drives torch.optim.AdamW on the same parameters to the same place (to rounding)
+    m3, _ = make()
+    m3.load_state_dict(sd_model)
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in m3.parameters()]
+    o3 = torch.optim.AdamW(ref, lr=2e-3, weight_decay=1e-2)
+    o3.load_state_dict(sd_opt)
+    m3.zero_grad()
+    loss(m3(x), t).backward()
+    for r, p in zip(ref, m3.parameters()):
+        r.grad = p.grad.detach().clone()
+    o3.step()
+    for r, p in zip(ref, m1.parameters()):
+        assert float((r.detach() - p.detach()).abs().max()) < 1e-6

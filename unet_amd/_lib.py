@@ -37,6 +37,13 @@ class MiStepInfo(C.Structure):
     ]
 
 
+class MiNormInfo(C.Structure):
+    _fields_ = [
+        ("raw_offset", C.c_int64), ("pitch", C.c_int32), ("coff", C.c_int32), ("c", C.c_int32), ("dtype", C.c_int32),
+        ("npix", C.c_int64), ("stats_offset", C.c_int64), ("layer", C.c_uint32),
+    ]
+
+
 class MiConvDesc(C.Structure):
     _fields_ = [
         ("ndim", C.c_int32), ("transposed", C.c_int32), ("ksize", C.c_int32), ("stride", C.c_int32),
@@ -75,6 +82,8 @@ PROTOTYPES = {
     "mi_unet_step_info": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(MiStepInfo)]),
     "mi_unet_step_output_offset": (C.c_int64, [_P, C.c_int, C.c_int]),
     "mi_unet_step_aux_offset": (C.c_int64, [_P, C.c_int, C.c_int]),
+    "mi_unet_num_norms": (C.c_int, [_P]),
+    "mi_unet_norm_info": (C.c_int, [_P, C.c_int, C.POINTER(MiNormInfo)]),
     "mi_dice_ce_loss_fwd": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float,
                                       C.c_float, _P, _P, _P, _P]),
     "mi_dice_ce_loss_bwd": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float,

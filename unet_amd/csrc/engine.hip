@@ -44,7 +44,7 @@ struct Reloc { size_t field_off; int base; };
 
 struct AddArgs { char* dst; int dpitch, dcoff; const char* src; int spitch, scoff, c; long long npix; };
 struct MemsetArgs { char* ptr; size_t bytes; };
-struct TabArgs { int first, count, max_elems; };   // max_elems: workgroups of the table launch
+struct TabArgs { int first, count; };   // range of descriptors a table step launches
 
 struct Step {
     int kind = 0, dtype = 0, bucket = 0;
@@ -108,13 +108,10 @@ struct mi_unet {
     // descriptor tables (pointer fields hold offsets until resolved)
     std::vector<PackDesc> packs; std::vector<int> pack_is_bwd;
     std::vector<ReduceDesc> reduces; std::vector<int> reduce_has_b;
-    std::vector<PackDesc> packs_res; std::vector<ReduceDesc> reduces_res;
-    size_t off_pack_tab = 0, off_reduce_tab = 0;
     size_t off_stats = 0, stats_bytes = 0, off_bstats = 0, bstats_bytes = 0;
-    char* cached_pack_bases[2] = {nullptr, nullptr};
-    char* cached_reduce_bases[2] = {nullptr, nullptr};
     double flops_fwd = 0, flops_bwd = 0;
     int n_fwd_packs = 0;
+    std::vector<mi_norm_info> norms;      // norm blocks of the forward pass in execution order
     // side stream for the weight-gradient launches of the backward pass (they depend only on tensors that are
     // final when they are issued and are joined in front of each bucket's slab reduction)
     hipStream_t side = nullptr;
@@ -164,7 +161,7 @@ struct Builder {
         d.dst = (void*)(uintptr_t)dst_off;
         d.N = N; d.K = K; d.ntaps = ntaps; d.sn = sn; d.sk = sk; d.Ntot = Ntot; d.Ktot = Ktot;
         d.n_off = n_off; d.k_off = k_off;
-        for (int i = 0; i < ntaps; ++i) d.kidx[i] = kidx[i];
+        for (int i = 0; i < ntaps; ++i) d.kidx[i] = (signed char)kidx[i];
         u.packs.push_back(d); u.pack_is_bwd.push_back(bwd ? 1 : 0);
     }
 
@@ -174,7 +171,7 @@ struct Builder {
         ReduceDesc d; memset(&d, 0, sizeof(d));
         d.partial = (const float*)(uintptr_t)partial_off; d.partial_bias = (const float*)(uintptr_t)pbias_off;
         d.nslab = nslab; d.ntaps = ntaps; d.Ftot = Ftot; d.S = S; d.f_off = f_off; d.Fcnt = Fcnt; d.KK = KKdst;
-        for (int i = 0; i < ntaps; ++i) d.kidx[i] = kidx ? kidx[i] : i;
+        for (int i = 0; i < ntaps; ++i) d.kidx[i] = (signed char)(kidx ? kidx[i] : i);
         d.dst_w = (float*)(uintptr_t)(poff(wname) * sizeof(float));
         int hasb = 0;
         if (!bname.empty()) { d.dst_b = (float*)(uintptr_t)(poff(bname) * sizeof(float)); hasb = 1; }
@@ -308,6 +305,13 @@ struct Builder {
         const int esz = dt ? 2 : 4;
         s.kernel = c == 1 ? "norm1_fwd_kernel" : (dt ? "norm_fwd_kernel<BF16>" : "norm_fwd_kernel<F32>");
         s.work = (double)u.nb * u.rp[res] * c * esz * (resid ? 3.0 : 2.0);
+        record_norm(res, c, dt, raw, stats_off, lid);
+    }
+    void record_norm(int res, int c, int dt, const Ten& raw, size_t stats_off, int lid) {
+        mi_norm_info ni; memset(&ni, 0, sizeof(ni));
+        ni.raw_offset = raw.base == B_ARENA ? (int64_t)raw.off : -1; ni.pitch = raw.pitch; ni.coff = raw.coff; ni.c = c;
+        ni.dtype = dt; ni.npix = u.rp[res]; ni.stats_offset = (int64_t)stats_off; ni.layer = (uint32_t)lid;
+        u.norms.push_back(ni);
     }
 
     void add_norm_bwd(const std::string& layer, int res, int c, int dt, const Ten& dy, const Ten& raw, size_t stats_off,
@@ -879,11 +883,8 @@ bool build(mi_unet& u) {
         B.push_reduce_step("reduce gradients: encoder bucket");
     }
 
-    // ---- descriptor tables ----
-    // reorder packs so that the forward packs come first (they already do: backward packs were appended later)
-    u.off_pack_tab = B.alloc(u.packs.size() * sizeof(PackDesc) + 256);
-    u.off_reduce_tab = B.alloc(u.reduces.size() * sizeof(ReduceDesc) + 256);
-    // reduces are grouped by their K_REDUCE step in creation order; find ranges
+    // ---- descriptor tables: the ranges of descriptors each table step launches ----
+    // reduces are grouped by their K_REDUCE step in creation order
     {
         std::vector<int> first(B.n_reduce_steps, -1), cnt(B.n_reduce_steps, 0);
         for (size_t i = 0; i < B.group_of_reduce.size(); ++i) {
@@ -896,13 +897,8 @@ bool build(mi_unet& u) {
         for (Step& s : u.bwd)
             if (s.kind == K_REDUCE) {
                 s.tab.first = first[k] < 0 ? 0 : first[k]; s.tab.count = cnt[k];
-                int blk = 0;
-                for (int i = s.tab.first; i < s.tab.first + s.tab.count; ++i) {
-                    ReduceDesc& d = u.reduces[i];
-                    d.blk0 = blk; d.nblk = reduce_blocks_for(d.ntaps * d.Fcnt * d.S + d.Fcnt);
-                    blk += d.nblk;
-                }
-                s.tab.max_elems = blk;
+                for (int i = s.tab.first; i < s.tab.first + s.tab.count; ++i)
+                    u.reduces[i].nblk = reduce_blocks_for(u.reduces[i].ntaps * u.reduces[i].Fcnt * u.reduces[i].S + u.reduces[i].Fcnt);
                 ++k;
             }
     }
@@ -910,13 +906,7 @@ bool build(mi_unet& u) {
         if (s.kind == K_PACK) {
             s.tab.first = 0; s.tab.count = (int)u.packs.size();  // forward and backward packs in one launch
             if (!train) s.tab.count = n_fwd_packs;
-            int blk = 0;
-            for (int i = 0; i < s.tab.count; ++i) {
-                PackDesc& d = u.packs[i];
-                d.blk0 = blk; d.nblk = pack_blocks_for(d.N * d.K);
-                blk += d.nblk;
-            }
-            s.tab.max_elems = blk;
+            for (int i = 0; i < s.tab.count; ++i) u.packs[i].nblk = pack_blocks_for(u.packs[i].N * u.packs[i].K);
         }
         if (s.kind == K_MEMSET) s.ms.bytes = align_up(B.stats_cursor, 16);
     }
@@ -926,31 +916,39 @@ bool build(mi_unet& u) {
     return true;
 }
 
-int upload_tables(mi_unet& u, char* const* bases, bool want_reduce, hipStream_t st) {
-    if (u.cached_pack_bases[0] != bases[B_ARENA] || u.cached_pack_bases[1] != bases[B_PARAMS]) {
-        u.packs_res = u.packs;
-        for (PackDesc& d : u.packs_res) {
+// Table steps: the descriptors of the step, pointers resolved against the caller's buffers, go out as kernel
+// arguments in chunks of one table per launch.
+int run_pack(mi_unet& u, const Step& s, char* const* bases, hipStream_t st) {
+    for (int i0 = s.tab.first; i0 < s.tab.first + s.tab.count; i0 += MI_PACK_TAB) {
+        PackTable t; memset(&t, 0, sizeof(t));
+        int blk = 0;
+        for (int i = i0; i < s.tab.first + s.tab.count && t.n < MI_PACK_TAB; ++i) {
+            PackDesc& d = t.d[t.n++];
+            d = u.packs[i];
             d.src = reinterpret_cast<const float*>(bases[B_PARAMS] + reinterpret_cast<uintptr_t>(d.src));
             d.dst = bases[B_ARENA] + reinterpret_cast<uintptr_t>(d.dst);
+            d.blk0 = blk; blk += d.nblk;
         }
-        if (!u.packs_res.empty())
-            MI_HIP(hipMemcpyAsync(bases[B_ARENA] + u.off_pack_tab, u.packs_res.data(), u.packs_res.size() * sizeof(PackDesc),
-                                  hipMemcpyHostToDevice, st));
-        u.cached_pack_bases[0] = bases[B_ARENA]; u.cached_pack_bases[1] = bases[B_PARAMS];
+        if (int r = launch_pack(s.dtype, t, blk, st)) return r;
     }
-    if (want_reduce && (u.cached_reduce_bases[0] != bases[B_ARENA] || u.cached_reduce_bases[1] != bases[B_GRADS])) {
-        u.reduces_res = u.reduces;
-        for (size_t i = 0; i < u.reduces_res.size(); ++i) {
-            ReduceDesc& d = u.reduces_res[i];
+    return 0;
+}
+
+int run_reduce(mi_unet& u, const Step& s, char* const* bases, hipStream_t st) {
+    if (!bases[B_GRADS]) { mi_set_error("gradient reduction needs the gradient buffer"); return -1; }
+    for (int i0 = s.tab.first; i0 < s.tab.first + s.tab.count; i0 += MI_REDUCE_TAB) {
+        ReduceTable t; memset(&t, 0, sizeof(t));
+        int blk = 0;
+        for (int i = i0; i < s.tab.first + s.tab.count && t.n < MI_REDUCE_TAB; ++i) {
+            ReduceDesc& d = t.d[t.n++];
+            d = u.reduces[i];
             d.partial = reinterpret_cast<const float*>(bases[B_ARENA] + reinterpret_cast<uintptr_t>(d.partial));
             d.partial_bias = reinterpret_cast<const float*>(bases[B_ARENA] + reinterpret_cast<uintptr_t>(d.partial_bias));
             d.dst_w = reinterpret_cast<float*>(bases[B_GRADS] + reinterpret_cast<uintptr_t>(d.dst_w));
             d.dst_b = u.reduce_has_b[i] ? reinterpret_cast<float*>(bases[B_GRADS] + reinterpret_cast<uintptr_t>(d.dst_b)) : nullptr;
+            d.blk0 = blk; blk += d.nblk;
         }
-        if (!u.reduces_res.empty())
-            MI_HIP(hipMemcpyAsync(bases[B_ARENA] + u.off_reduce_tab, u.reduces_res.data(),
-                                  u.reduces_res.size() * sizeof(ReduceDesc), hipMemcpyHostToDevice, st));
-        u.cached_reduce_bases[0] = bases[B_ARENA]; u.cached_reduce_bases[1] = bases[B_GRADS];
+        if (int r = launch_reduce(t, blk, st)) return r;
     }
     return 0;
 }
@@ -982,12 +980,8 @@ int run_step(mi_unet& u, Step& s, char* const* bases, int training, uint64_t see
             if (m.bytes) MI_HIP(hipMemsetAsync(m.ptr, 0, m.bytes, st));
             return 0;
         }
-        case K_REDUCE:
-            return launch_reduce(reinterpret_cast<const ReduceDesc*>(bases[B_ARENA] + u.off_reduce_tab) + s.tab.first,
-                                 s.tab.count, s.tab.max_elems, st);
-        case K_PACK:
-            return launch_pack(s.dtype, reinterpret_cast<const PackDesc*>(bases[B_ARENA] + u.off_pack_tab) + s.tab.first,
-                               s.tab.count, s.tab.max_elems, st);
+        case K_REDUCE: return run_reduce(u, s, bases, st);
+        case K_PACK: return run_pack(u, s, bases, st);
     }
     mi_set_error("unknown step kind");
     return -1;
@@ -1149,7 +1143,6 @@ int mi_unet_forward(mi_unet* u, const float* params, const float* x, float* logi
     char* bases[B_NBASE] = {nullptr};
     bases[B_ARENA] = (char*)workspace; bases[B_PARAMS] = (char*)params; bases[B_XIN] = (char*)x; bases[B_LOGITS] = (char*)logits;
     hipStream_t st = (hipStream_t)stream;
-    if (int r = upload_tables(*u, bases, false, st)) return r;
     return run_list(*u, u->fwd, 0, -1, bases, training, seed, st);
 }
 
@@ -1162,7 +1155,6 @@ int mi_unet_backward(mi_unet* u, const float* params, const float* x, const floa
     bases[B_ARENA] = (char*)workspace; bases[B_PARAMS] = (char*)params; bases[B_GRADS] = (char*)grads;
     bases[B_DLOGITS] = (char*)dlogits; bases[B_XIN] = (char*)x;
     hipStream_t st = (hipStream_t)stream;
-    if (int r = upload_tables(*u, bases, true, st)) return r;
     return run_list(*u, u->bwd, 1, bucket, bases, training, seed, st);
 }
 
@@ -1196,6 +1188,13 @@ int64_t mi_unet_step_aux_offset(const mi_unet* u, int backward, int i) {
     if (s.kind == K_NORM_BWD) return (int64_t)(uintptr_t)s.nm.bstats;
     if (s.kind == K_NORM_FWD) return (int64_t)(uintptr_t)s.nm.stats;
     return -1;
+}
+
+int mi_unet_num_norms(const mi_unet* u) { return (int)u->norms.size(); }
+int mi_unet_norm_info(const mi_unet* u, int k, mi_norm_info* info) {
+    MI_CHECK(u && info && k >= 0 && k < (int)u->norms.size(), "bad index");
+    *info = u->norms[k];
+    return 0;
 }
 
 int mi_unet_prof_enable(mi_unet* u, int on) { u->prof = on != 0; return 0; }

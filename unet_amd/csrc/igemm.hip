@@ -950,16 +950,16 @@ __device__ __forceinline__ void reduce_body(const ReduceDesc& d, int blk, int nb
 template <class TR>
 __device__ __forceinline__ void pack_body(const PackDesc& d, int blk, int nblk);
 // one launch for a table of descriptors: workgroup b serves the descriptor whose range [blk0, blk0 + nblk) holds b
-__global__ __launch_bounds__(256) void reduce_kernel(const ReduceDesc* __restrict__ descs, int ndesc) {
+__global__ __launch_bounds__(256) void reduce_kernel(const ReduceTable tab) {
     int i = 0;
-    while (i + 1 < ndesc && (int)blockIdx.x >= descs[i + 1].blk0) ++i;
-    reduce_body(descs[i], (int)blockIdx.x - descs[i].blk0, descs[i].nblk);
+    while (i + 1 < tab.n && (int)blockIdx.x >= tab.d[i + 1].blk0) ++i;
+    reduce_body(tab.d[i], (int)blockIdx.x - tab.d[i].blk0, tab.d[i].nblk);
 }
 template <class TR>
-__global__ __launch_bounds__(256) void pack_kernel(const PackDesc* __restrict__ descs, int ndesc) {
+__global__ __launch_bounds__(256) void pack_kernel(const PackTable tab) {
     int i = 0;
-    while (i + 1 < ndesc && (int)blockIdx.x >= descs[i + 1].blk0) ++i;
-    pack_body<TR>(descs[i], (int)blockIdx.x - descs[i].blk0, descs[i].nblk);
+    while (i + 1 < tab.n && (int)blockIdx.x >= tab.d[i + 1].blk0) ++i;
+    pack_body<TR>(tab.d[i], (int)blockIdx.x - tab.d[i].blk0, tab.d[i].nblk);
 }
 
 // 256 threads = EL output elements x SG slab groups (EL = 64, 16, 4 or 1: few outputs with many slabs get more
@@ -1326,9 +1326,10 @@ int reduce_blocks_for(int total) {
 }
 
 // total_blocks: sum of the descriptors' nblk (each set from reduce_blocks_for(), blk0 = running sum)
-int launch_reduce(const ReduceDesc* d_descs, int ndesc, int total_blocks, hipStream_t st) {
-    if (ndesc <= 0 || total_blocks <= 0) return 0;
-    hipLaunchKernelGGL(reduce_kernel, dim3(total_blocks), dim3(256), 0, st, d_descs, ndesc);
+int launch_reduce(const ReduceTable& tab, int total_blocks, hipStream_t st) {
+    if (tab.n <= 0 || total_blocks <= 0) return 0;
+    static_assert(sizeof(ReduceTable) <= 4096 && sizeof(PackTable) <= 4096, "descriptor tables must fit the kernel argument segment");
+    hipLaunchKernelGGL(reduce_kernel, dim3(total_blocks), dim3(256), 0, st, tab);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { mi_set_error(std::string("reduce launch: ") + hipGetErrorString(e)); return -2; }
     return 0;
@@ -1341,10 +1342,10 @@ int pack_blocks_for(int pairs) {
 }
 
 // total_blocks: sum of the descriptors' nblk (each set from pack_blocks_for(), blk0 = running sum)
-int launch_pack(int dtype, const PackDesc* d_descs, int ndesc, int total_blocks, hipStream_t st) {
-    if (ndesc <= 0 || total_blocks <= 0) return 0;
-    if (dtype) hipLaunchKernelGGL(pack_kernel<BF16>, dim3(total_blocks), dim3(256), 0, st, d_descs, ndesc);
-    else hipLaunchKernelGGL(pack_kernel<F32>, dim3(total_blocks), dim3(256), 0, st, d_descs, ndesc);
+int launch_pack(int dtype, const PackTable& tab, int total_blocks, hipStream_t st) {
+    if (tab.n <= 0 || total_blocks <= 0) return 0;
+    if (dtype) hipLaunchKernelGGL(pack_kernel<BF16>, dim3(total_blocks), dim3(256), 0, st, tab);
+    else hipLaunchKernelGGL(pack_kernel<F32>, dim3(total_blocks), dim3(256), 0, st, tab);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { mi_set_error(std::string("pack launch: ") + hipGetErrorString(e)); return -2; }
     return 0;

@@ -64,7 +64,7 @@ struct WgradParams {
 struct ReduceDesc {
     const float* partial; const float* partial_bias;
     int nslab, ntaps, Ftot, S, f_off, Fcnt, KK;
-    int kidx[MI_MAX_TAPS];
+    signed char kidx[MI_MAX_TAPS + 1];
     float* dst_w; float* dst_b;             // dst_b may be null
     int blk0, nblk;                         // table launches: this descriptor owns workgroups [blk0, blk0 + nblk) of its launch
 };
@@ -73,9 +73,16 @@ struct ReduceDesc {
 struct PackDesc {
     const float* src; void* dst;
     int N, K, ntaps, sn, sk, Ntot, Ktot, n_off, k_off;
-    int kidx[MI_MAX_TAPS];
+    signed char kidx[MI_MAX_TAPS + 1];
     int blk0, nblk;                         // table launches: this descriptor owns workgroups [blk0, blk0 + nblk) of its launch
 };
+
+// Descriptor tables travel as kernel arguments (by value, under 4 KiB): nothing is staged in device memory, so a
+// launch never depends on what an earlier call left behind in a workspace.
+#define MI_PACK_TAB 40
+#define MI_REDUCE_TAB 36
+struct PackTable { int n, pad; PackDesc d[MI_PACK_TAB]; };
+struct ReduceTable { int n, pad; ReduceDesc d[MI_REDUCE_TAB]; };
 
 // Instance-norm + PReLU (+dropout, +residual) launch
 struct NormParams {
@@ -136,9 +143,9 @@ struct StencilParams {
 extern "C++" {
 int launch_igemm(int dtype, const IgemmParams& p, hipStream_t st);
 int launch_wgrad(int dtype, const WgradParams& p, hipStream_t st);
-int launch_reduce(const ReduceDesc* d_descs, int ndesc, int total_blocks, hipStream_t st);
+int launch_reduce(const ReduceTable& tab, int total_blocks, hipStream_t st);   // total_blocks: sum of the descriptors' nblk
 int reduce_blocks_for(int total);
-int launch_pack(int dtype, const PackDesc* d_descs, int ndesc, int total_blocks, hipStream_t st);
+int launch_pack(int dtype, const PackTable& tab, int total_blocks, hipStream_t st);
 int pack_blocks_for(int pairs);
 int launch_reduce_one(const ReduceDesc& d, hipStream_t st);
 int c1_wgrad_slabs(int N, const int cd[3]);

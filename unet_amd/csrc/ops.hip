@@ -51,7 +51,7 @@ int mi_conv_pack(const mi_conv_desc* d, int dgrad, const float* w, void* packed,
     const int KK = ktaps(s);
     PackDesc p; memset(&p, 0, sizeof(p));
     p.src = w; p.dst = packed; p.ntaps = ntaps;
-    for (int i = 0; i < ntaps; ++i) p.kidx[i] = kidx[i];
+    for (int i = 0; i < ntaps; ++i) p.kidx[i] = (signed char)kidx[i];
     // element (co, ci, k) of the torch tensor: conv [co][ci][k], transposed conv [ci][co][k]
     const int s_co = d->transposed ? KK : d->cin * KK;
     const int s_ci = d->transposed ? d->cout * KK : KK;
@@ -126,7 +126,7 @@ int mi_conv_wgrad(const mi_conv_desc* d, const mi_tensor* x, const mi_tensor* dy
     ReduceDesc rd; memset(&rd, 0, sizeof(rd));
     rd.partial = p.partial; rd.partial_bias = p.partial_bias; rd.nslab = (int)slabs; rd.ntaps = p.ntaps_total;
     rd.Ftot = p.F; rd.S = p.S; rd.f_off = 0; rd.Fcnt = p.F; rd.KK = p.ntaps_total;
-    for (int i = 0; i < p.ntaps_total; ++i) rd.kidx[i] = i;
+    for (int i = 0; i < p.ntaps_total; ++i) rd.kidx[i] = (signed char)i;
     rd.dst_w = dw; rd.dst_b = (db && !d->transposed) ? db : nullptr;
     return launch_reduce_one(rd, (hipStream_t)stream);
 }

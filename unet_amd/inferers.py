@@ -55,11 +55,15 @@ def shard_range(n_items: int, rank: int, world: int):
 SW_GROUP_WINDOWS = 288   # windows per model call when the predictor is known to treat samples independently
 
 
-def _windows_per_call(predictor, sw_batch_size: int, total: int, window_elems: int) -> int:
-    """MONAI's ``sw_batch_size`` only bounds memory.  For this package's U-Net in eval mode every window is an
+def _windows_per_call(predictor, sw_batch_size: int, total: int, window_elems: int):
+    """(windows per model call, pad the last call to that size).
+
+    MONAI's ``sw_batch_size`` only bounds memory.  For this package's U-Net in eval mode every window is an
     independent sample (instance norm, dropout off), so a larger group gives the same numbers in fewer, fuller
-    launches; any other predictor gets exactly the group size it was asked for (``UNET_AMD_SW_EXACT=1`` forces
-    that for the U-Net too)."""
+    launches.  The group size is then a power of two (or the maximum), and a short last group is padded with
+    zero windows whose outputs are dropped: whatever the image size, the U-Net sees only a handful of batch
+    sizes and builds only that many engine plans.  Any other predictor gets exactly the group size it was asked
+    for and an unpadded tail (``UNET_AMD_SW_EXACT=1`` forces that for the U-Net too)."""
     import os
 
     from .nets import UNet
@@ -67,8 +71,12 @@ def _windows_per_call(predictor, sw_batch_size: int, total: int, window_elems: i
     n = max(1, int(sw_batch_size))
     if isinstance(predictor, UNet) and not predictor.training and os.environ.get("UNET_AMD_SW_EXACT", "0") != "1":
         cap = max(1, (1 << 28) // max(1, window_elems))       # keep one group's input below 1 GiB of fp32
-        n = max(n, min(total, SW_GROUP_WINDOWS, cap))
-    return n
+        top = max(n, min(SW_GROUP_WINDOWS, cap))
+        g = 1
+        while g < total and g < top:
+            g *= 2
+        return min(g, top), True
+    return n, False
 
 
 def sliding_window_inference(inputs: torch.Tensor, roi_size, sw_batch_size: int,
@@ -109,10 +117,13 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size, sw_batch_size: int,
         rpix *= r
     win_out = torch.empty((total, 1) + tuple(roi), dtype=torch.float32, device=dev)
     stream = _lib.current_stream(dev)
-    group = _windows_per_call(predictor, sw_batch_size, total, rpix)
+    group, pad_tail = _windows_per_call(predictor, sw_batch_size, total, rpix)
     for g in range(0, total, group):
         n = min(group, total - g)
-        wins = torch.empty((n, 1) + tuple(roi), dtype=torch.float32, device=dev)
+        if n < group and pad_tail:
+            wins = torch.zeros((group, 1) + tuple(roi), dtype=torch.float32, device=dev)
+        else:
+            wins = torch.empty((n, 1) + tuple(roi), dtype=torch.float32, device=dev)
         _lib.check(lib.mi_sw_gather(x.data_ptr(), wins.data_ptr(), starts_dev.data_ptr(), nwin, g, n, nb, img3, roi3,
                                     pad3, float(cval), stream), "mi_sw_gather")
         pred = predictor(wins)
@@ -120,7 +131,7 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size, sw_batch_size: int,
             pred = pred[0]
         if pred.shape != wins.shape:
             raise NotImplementedError("the predictor must keep the window shape (one output channel)")
-        win_out[g:g + n].copy_(pred)
+        win_out[g:g + n].copy_(pred[:n])
     out = torch.empty((nb, 1) + tuple(img), dtype=torch.float32, device=dev)
     _lib.check(lib.mi_sw_blend(win_out.data_ptr(), out.data_ptr(), starts_dev.data_ptr(), nwin, nb, img3, roi3, pad3,
                                stream), "mi_sw_blend")

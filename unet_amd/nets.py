@@ -13,6 +13,7 @@ import ctypes as C
 import os
 import threading
 import weakref
+from collections import OrderedDict
 from typing import Sequence
 
 import torch
@@ -172,8 +173,14 @@ class _Plan:
         return torch.empty(self.workspace_bytes, dtype=torch.uint8, device=device)
 
     def give_workspace(self, ws):
+        """Keeps at most one idle workspace per plan; the rest goes back to torch's allocator."""
         with self._lock:
-            self._pool.append(ws)
+            if not self._pool:
+                self._pool.append(ws)
+
+    def drop_workspaces(self):
+        with self._lock:
+            self._pool.clear()
 
     def forward(self, flat, x, logits, ws, training, seed):
         _lib.check(self.lib.mi_unet_forward(self.h, flat.data_ptr(), x.data_ptr(), logits.data_ptr(), ws.data_ptr(),
@@ -227,7 +234,8 @@ class _UNetFunction(torch.autograd.Function):
         dlogits = dlogits.contiguous()
         if dlogits.dtype != torch.float32:
             dlogits = dlogits.float()
-        g = torch.empty_like(model._flat)
+        # zero-filled: parameter offsets are padded to 16 bytes and the engine never writes the gaps
+        g = torch.zeros_like(model._flat)
         plan.backward(model._flat, ctx.x, dlogits, g, ctx.lease.ws, ctx.training, ctx.seed)
         model._last_grad_flat = g
         grads = tuple(g[o:o + n].view(s) for (_, s, n, o, _) in model._ptable_ordered)
@@ -311,7 +319,7 @@ class UNet(nn.Module):
         self._cfg_kwargs = dict(spatial_dims=spatial_dims, in_channels=in_channels, out_channels=out_channels,
                                 channels=self.channels, strides=self.strides, num_res_units=num_res_units,
                                 dropout=self.dropout)
-        self._plans = {}
+        self._plans = OrderedDict()     # least recently used first; bounded by MAX_PLANS
         self._flat = None
         self._ptable = None           # state_dict order: (name, shape, numel, offset, bucket)
         self._ptable_ordered = None   # same entries in self.parameters() order
@@ -378,15 +386,25 @@ class UNet(nn.Module):
         self._layout()
         return list(self._buckets)
 
+    MAX_PLANS = 8     # engine plans (one per batch size / spatial size / direction set) kept per model
+
     def _plan_for(self, x, with_backward):
         key = (x.shape[0], tuple(x.shape[2:]), _DT[self.compute_dtype], bool(with_backward))
-        plan = self._plans.get(key)
+        plans = self._plans
+        plan = plans.get(key)
+        if plan is None and not with_backward:
+            key_bwd = key[:3] + (True,)
+            if key_bwd in plans:
+                key, plan = key_bwd, plans[key_bwd]
         if plan is None:
-            alt = self._plans.get(key[:3] + (True,)) if not with_backward else None
-            if alt is not None:
-                return alt
             plan = _Plan(self._cfg_kwargs, key[0], key[1], key[2], with_backward)
-            self._plans[key] = plan
+            plans[key] = plan
+            limit = max(1, int(os.environ.get("UNET_AMD_MAX_PLANS", self.MAX_PLANS)))
+            while len(plans) > limit:
+                _, old = plans.popitem(last=False)      # its engine and idle workspace go when the last user lets go
+                old.drop_workspaces()
+        else:
+            plans.move_to_end(key)
         return plan
 
     def _check_input(self, x):

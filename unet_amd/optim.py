@@ -56,6 +56,48 @@ class AdamW(torch.optim.Optimizer):
                 self._gflat[o:o + n].view(s).copy_(p.grad)
         return self._gflat
 
+    # ---- checkpointing: torch.optim.AdamW's own format ---------------------------------------------------------
+    def state_dict(self):
+        """``{"state": {i: {"step", "exp_avg", "exp_avg_sq"}}, "param_groups": [...]}`` as ``torch.optim.AdamW``
+        writes it (one entry per parameter, in ``model.parameters()`` order), so the file loads into either."""
+        base = super().state_dict()
+        state = {}
+        if self._m is not None and self._model is not None:
+            table = self._model._ptable_ordered
+            for i, (_, shp, n, o, _) in enumerate(table):
+                state[i] = {"step": torch.tensor(float(self._step)),
+                            "exp_avg": self._m[o:o + n].view(shp).clone(),
+                            "exp_avg_sq": self._v[o:o + n].view(shp).clone()}
+        base["state"] = state
+        return base
+
+    def load_state_dict(self, state_dict):
+        model = self._model
+        if model is None:
+            raise RuntimeError("unet_amd.AdamW: call bind(model) or pass model= at construction before load_state_dict")
+        state = state_dict.get("state", {})
+        super().load_state_dict({"state": {}, "param_groups": state_dict["param_groups"]})
+        if not state:
+            self._step, self._m, self._v = 0, None, None
+            return
+        params = self.param_groups[0]["params"]
+        flat = model._ensure_flat(params[0].device)
+        table = model._ptable_ordered
+        if len(state) != len(table):
+            raise ValueError(f"optimizer state holds {len(state)} parameters, the UNet has {len(table)}")
+        m, v = torch.zeros_like(flat), torch.zeros_like(flat)
+        steps = set()
+        for i, (name, shp, n, o, _) in enumerate(table):
+            st = state[i] if i in state else state[str(i)]
+            if tuple(st["exp_avg"].shape) != tuple(shp):
+                raise ValueError(f"optimizer state of {name}: shape {tuple(st['exp_avg'].shape)} != {tuple(shp)}")
+            m[o:o + n].view(shp).copy_(st["exp_avg"])
+            v[o:o + n].view(shp).copy_(st["exp_avg_sq"])
+            steps.add(int(float(st["step"])))
+        if len(steps) != 1:
+            raise ValueError("unet_amd.AdamW keeps one step counter: the loaded parameters disagree on it")
+        self._m, self._v, self._step = m, v, steps.pop()
+
     @torch.no_grad()
     def step(self, closure=None, *, flat_grad=None, grad_scale: float = 1.0):
         loss = None

@@ -42,19 +42,25 @@ class BucketedAllReduce:
     ``launch(i)`` must be called after the work that produces bucket ``i`` has been enqueued on the
     current stream; ``wait()`` makes the current stream (GPU) or the host (CPU tensors) wait for all
     launched buckets.  Averaging is left to the consumer (the fused AdamW takes ``grad_scale``).
+
+    Every collective is issued with ``async_op=True`` and only ``wait()`` waits: ``launch`` never blocks the
+    host, whatever the backend, so the kernels of the following buckets are enqueued without waiting for a
+    peer (with a backend whose collectives complete on the host, such as gloo on device tensors, a blocking
+    call per bucket would stall the enqueue of the rest of the backward pass behind the slowest rank).
+    ``force=True`` runs the collectives even in a group of one rank (tests of the stream / event ordering).
     """
 
-    def __init__(self, flat: torch.Tensor, buckets: Sequence[Tuple[int, int]], group=None):
+    def __init__(self, flat: torch.Tensor, buckets: Sequence[Tuple[int, int]], group=None, force: bool = False):
         self.flat = flat
         self.buckets = [(int(o), int(c)) for o, c in buckets]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.force = bool(force) and dist.is_initialized()
         self._works: List = []
         self._comm_stream = torch.cuda.Stream(flat.device) if flat.is_cuda else None
-        self._events: List = []
 
     def launch(self, i: int) -> None:
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         o, c = self.buckets[i]
         if c == 0:
@@ -65,22 +71,24 @@ class BucketedAllReduce:
             ready.record(torch.cuda.current_stream(self.flat.device))
             with torch.cuda.stream(self._comm_stream):
                 self._comm_stream.wait_event(ready)
-                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
-                done = torch.cuda.Event()
-                done.record(self._comm_stream)
-            self._events.append(done)
+                self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
             self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait(self) -> None:
-        for w in self._works:
-            w.wait()
+        if not self._works:
+            return
+        if self._comm_stream is not None:
+            with torch.cuda.stream(self._comm_stream):
+                for w in self._works:
+                    w.wait()              # RCCL: the communication stream waits; host-side backends: the host does
+                done = torch.cuda.Event()
+                done.record(self._comm_stream)
+            torch.cuda.current_stream(self.flat.device).wait_event(done)
+        else:
+            for w in self._works:
+                w.wait()
         self._works = []
-        if self._events:
-            cur = torch.cuda.current_stream(self.flat.device)
-            for e in self._events:
-                cur.wait_event(e)
-            self._events = []
 
 
 def shard_batch(n: int, rank: int, world: int) -> Tuple[int, int]:

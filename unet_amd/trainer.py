@@ -21,11 +21,15 @@ from .parallel import BucketedAllReduce
 
 
 class Trainer:
-    def __init__(self, model: UNet, loss: DiceCELoss, optimizer: AdamW, *, group=None, overlap: bool = True):
+    def __init__(self, model: UNet, loss: DiceCELoss, optimizer: AdamW, *, group=None, overlap: bool = True,
+                 force_reducer: bool = False):
+        """``force_reducer``: run the bucketed all-reduce path even in a process group of one rank (it then
+        exercises the bucket-by-bucket backward, the communication stream and its events; the sums are unchanged)."""
         self.model, self.loss, self.opt = model, loss, optimizer
         optimizer.bind(model)
         self.group = group
         self.overlap = overlap
+        self.force_reducer = force_reducer
         self._bufs = {}
         self._reducer = None
         self._grad = None
@@ -82,7 +86,8 @@ class Trainer:
         if self._grad is None or self._grad.device != dev:
             self._grad = torch.zeros_like(flat)
             self._loss_accum = torch.zeros(1, dtype=torch.float32, device=dev)
-            self._reducer = BucketedAllReduce(self._grad, model.gradient_buckets(), self.group) if self.world > 1 else None
+            self._reducer = (BucketedAllReduce(self._grad, model.gradient_buckets(), self.group, force=self.force_reducer)
+                             if (self.world > 1 or self.force_reducer) else None)
         st = _lib.current_stream(dev)
         # every rank draws its own dropout masks
         seed = (model._next_seed() + 0x9E3779B97F4A7C15 * self.rank) & 0xFFFFFFFFFFFFFFFF
