@@ -51,21 +51,31 @@ def record_preactivations(model: nn.Module, x: torch.Tensor) -> List[torch.Tenso
 
 @contextlib.contextmanager
 def inject(model: nn.Module, x: torch.Tensor, decisions: Optional[Sequence[torch.Tensor]] = None,
-           keep: Optional[Sequence[torch.Tensor]] = None, p: float = 0.0):
+           keep: Optional[Sequence[torch.Tensor]] = None, p: float = 0.0, slope_mass: Optional[dict] = None):
     """Inside the context the k-th block multiplies by ``keep[k] / (1 - p)`` instead of drawing a dropout mask
     (when ``keep`` is given) and takes the PReLU branch ``decisions[k]`` (True: identity side) instead of
-    testing the sign (when ``decisions`` is given)."""
+    testing the sign (when ``decisions`` is given).  ``slope_mass`` (a dict) receives, per PReLU module, the sum
+    of the absolute values of the terms whose signed sum is the gradient of that module's slope: the scale
+    against which the rounding error of that one-scalar reduction has to be read when its terms cancel."""
     blocks = adn_blocks(model, x)
     saved = []
     for k, b in enumerate(blocks):
         if keep is not None and hasattr(b, "D"):
-            mask = keep[k].to(x.dtype) / (1.0 - p)
+            mask = keep[k].contiguous().to(x.dtype) / (1.0 - p)
             saved.append((b.D, b.D.forward))
             b.D.forward = (lambda t, mask=mask: t * mask)
         if decisions is not None:
-            dec = decisions[k]
+            dec = decisions[k].contiguous()     # dense channels-first: torch's CPU conv3d backward mishandles channels-last-3d strided inputs
             saved.append((b.A, b.A.forward))
-            b.A.forward = (lambda t, dec=dec, act=b.A: torch.where(dec, t, act.weight * t))
+
+            def fwd(t, dec=dec, act=b.A):
+                out = torch.where(dec, t, act.weight * t)
+                if slope_mass is not None and out.requires_grad:
+                    neg = torch.where(dec, torch.zeros_like(t), t).detach()
+                    out.register_hook(lambda g, neg=neg, act=act: slope_mass.__setitem__(act, float((g * neg).abs().sum())))
+                return out
+
+            b.A.forward = fwd
     try:
         yield blocks
     finally:

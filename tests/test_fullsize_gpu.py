@@ -82,8 +82,10 @@ def test_nine_window_sliding_inference_full_size(dev):
     # constant predictor: every pixel is an average of equal constants
     out = unet_amd.sliding_window_inference(x, (256, 256), 4, lambda w: torch.full_like(w, 3.25))
     assert torch.equal(out, torch.full_like(x, 3.25))
-    # per-window forward of the U-Net (one window per call), accumulated and divided by the cover count in torch
-    m = _model(torch.bfloat16, dev).eval()
+    # per-window forward of the U-Net (one window per call), accumulated and divided by the cover count in torch;
+    # fp32 storage: a batch of one window takes other kernel variants (contraction split) than a batch of 36, and
+    # only fp32 keeps that change of summation order at rounding level
+    m = _model(torch.float32, dev).eval()
     with torch.no_grad():
         got = unet_amd.sliding_window_inference(x, (256, 256), 4, m)
         acc = torch.zeros_like(x, dtype=torch.float64)
@@ -93,9 +95,9 @@ def test_nine_window_sliding_inference_full_size(dev):
                 y = m(x[b:b + 1, :, sy:sy + 256, sx:sx + 256].contiguous())
                 acc[b:b + 1, :, sy:sy + 256, sx:sx + 256] += y.double()
                 cnt[b:b + 1, :, sy:sy + 256, sx:sx + 256] += 1
-    assert float(cnt.min()) == 1 and float(cnt.max()) == 9
+    assert float(cnt.min()) == 1 and float(cnt.max()) == 4          # starts 0, 192, 256: at most two windows per axis
     ref = (acc / cnt).float()
-    assert float((got - ref).abs().max()) <= 2e-6 * float(ref.abs().max())      # same window outputs; fp32 vs fp64 averaging
+    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
 
 
 def test_directional_derivative_matches_gradient_fp32(dev):
