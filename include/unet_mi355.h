@@ -127,6 +127,15 @@ int mi_dice_ce_loss_bwd(const float* logits, const void* target, int target_dtyp
                         int64_t npix, float smooth_nr, float smooth_dr, float lambda_dice, float lambda_ce,
                         const double* sums, const float* grad_out /* optional device scalar */, float grad_scale,
                         float* dlogits, void* stream);
+/* Loss forward for callers that cannot allocate.  No counterpart in the reference: it serves callers of this
+ * library that may not call hipMalloc or bring a workspace (code under HIP graph capture, tight serving /
+ * validation loops, harnesses that forbid allocation).  Same arithmetic and kernels as mi_dice_ce_loss_fwd, but the
+ * per-sample sums live in a device array inside the library (128 KiB per GPU, held until the process ends), so
+ * nb <= 4096 (larger batches are refused with an error) and no backward pass can follow from it.  Calls on one GPU
+ * share that GPU's array: the array is cleared at the start of every call, and calls that overlap on one GPU race. */
+int mi_dice_ce_loss_fwd_noalloc(const float* logits, const void* target, int target_dtype, int fold2, int nb,
+                                int64_t npix, float smooth_nr, float smooth_dr, float lambda_dice, float lambda_ce,
+                                float* loss /* [1] */, float* loss_accum /* optional running sum */, void* stream);
 int mi_dice_counts(const float* pred, int pred_is_binary, float thresh, const void* target, int target_dtype,
                    int fold2, int nb, int64_t npix, uint64_t* counts /* [nb][4] tp,fp,fn,tn */, void* stream);
 int mi_fold_labels(void* target, int target_dtype, int64_t n, void* stream);

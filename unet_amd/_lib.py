@@ -88,6 +88,8 @@ PROTOTYPES = {
                                       C.c_float, _P, _P, _P, _P]),
     "mi_dice_ce_loss_bwd": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float,
                                       C.c_float, _P, _P, C.c_float, _P, _P]),
+    "mi_dice_ce_loss_fwd_noalloc": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float,
+                                              C.c_float, _P, _P, _P]),
     "mi_dice_counts": (C.c_int, [_P, C.c_int, C.c_float, _P, C.c_int, C.c_int, C.c_int, C.c_int64, _P, _P]),
     "mi_fold_labels": (C.c_int, [_P, C.c_int, C.c_int64, _P]),
     "mi_adamw_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,

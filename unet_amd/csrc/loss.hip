@@ -1,6 +1,10 @@
 // Reductions and element-wise kernels around the network: sigmoid-Dice(+BCE) loss forward /
 // backward, hard-Dice confusion counts, AdamW over a flat parameter buffer, sliding-window
 // crop / blend, and small utilities.  All HBM-bound; 16-byte accesses where the layout allows.
+#include <string.h>
+
+#include <mutex>
+
 #include "common.h"
 #include "kparams.h"
 #include "lossparams.h"
@@ -283,6 +287,52 @@ int launch_loss_fwd(const LossParams& p, hipStream_t st) {
     if (int r = check_launch("loss_reduce")) return r;
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, p);
     return check_launch("loss_finalize");
+}
+
+// ---- loss forward for callers that cannot allocate ---------------------------------------------------------------
+// The per-sample sums of the loss are scratch memory (partial results beyond inputs and outputs).  This variant
+// keeps them in a file-scope device array instead of a caller buffer, so a caller under stream capture or inside a
+// serving loop needs no workspace.  Every GPU the library runs on holds its own copy of the array at its own
+// address until the process ends; host code only ever uses the address obtained per device below, never the
+// array's name.  Calls on one GPU share that GPU's array: calls that overlap on one GPU race.
+#define MI_NOALLOC_MAX_BATCH 4096
+static __device__ __align__(256) double g_loss_scratch[MI_NOALLOC_MAX_BATCH * 4];     // 128 KiB per GPU
+
+namespace {
+constexpr int kMaxDevices = 64;
+double* g_loss_scratch_ptr[kMaxDevices] = {nullptr};
+std::mutex g_loss_scratch_mu;
+
+// device address of this GPU's copy of the scratch array (looked up once per device, with that device current)
+int loss_scratch_for_current_device(double** out) {
+    int dev = -1;
+    MI_HIP(hipGetDevice(&dev));
+    MI_CHECK(dev >= 0 && dev < kMaxDevices, "device ordinal out of range");
+    std::lock_guard<std::mutex> lock(g_loss_scratch_mu);
+    if (!g_loss_scratch_ptr[dev]) {
+        void* p = nullptr;
+        MI_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(g_loss_scratch)));
+        MI_CHECK(p != nullptr, "hipGetSymbolAddress returned a null address");
+        g_loss_scratch_ptr[dev] = static_cast<double*>(p);
+    }
+    *out = g_loss_scratch_ptr[dev];
+    return 0;
+}
+}  // namespace
+
+extern "C" int mi_dice_ce_loss_fwd_noalloc(const float* logits, const void* target, int target_dtype, int fold2, int nb,
+                                           int64_t npix, float smooth_nr, float smooth_dr, float lambda_dice, float lambda_ce,
+                                           float* loss, float* loss_accum, void* stream) {
+    MI_CHECK(logits && target && loss, "null argument");
+    MI_CHECK(npix > 0 && npix < 2147483647LL && nb > 0, "bad sizes");
+    MI_CHECK(nb <= MI_NOALLOC_MAX_BATCH, "batch exceeds the 4096 samples the built-in scratch array holds: use mi_dice_ce_loss_fwd with a caller buffer");
+    double* sums = nullptr;
+    if (int r = loss_scratch_for_current_device(&sums)) return r;
+    LossParams p; memset(&p, 0, sizeof(p));
+    p.logits = logits; p.target = target; p.tdtype = target_dtype; p.fold2 = fold2; p.sums = sums; p.loss = loss;
+    p.loss_accum = loss_accum; p.nb = nb; p.npix = (int)npix; p.smooth_nr = smooth_nr; p.smooth_dr = smooth_dr;
+    p.lambda_dice = lambda_dice; p.lambda_ce = lambda_ce;
+    return launch_loss_fwd(p, (hipStream_t)stream);       // clears sums[0 .. 4*nb) on the stream, then accumulates
 }
 
 int launch_loss_bwd(const LossParams& p, hipStream_t st) {
