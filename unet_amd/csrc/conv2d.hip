@@ -1,0 +1,431 @@
+// Two-dimensional gather-GEMM convolution with asynchronous staging (gfx950).
+//
+// Same contract as igemm_kernel (kparams.h, IgemmParams) for 2-D tensors gathered with unit stride and a 16 x 16
+// pixel tile: 3 x 3 taps (18 x 18 patch) or one tap.  What differs from the register-staged kernels of igemm.hip:
+//
+//  * the input patch and the weight tile of a stage go from global memory straight into LDS (global_load ... lds,
+//    16 bytes per lane, no registers in between), the loads of stage s + 1 are issued before the MFMA loop of
+//    stage s and land while it runs: one barrier per stage, and a workgroup that walks several tiles has the next
+//    tile's patch in flight during the current tile's arithmetic and epilogue;
+//  * LDS rows are unpadded 64-byte pixel (or weight) rows; the 16-byte chunk c of row r sits in slot
+//    c ^ (((x >> 2) & 1) << 1), x = the pixel's column in the patch (the row number for weights).  The DMA writes LDS lane-linearly, so the permutation is applied to the per-lane
+//    SOURCE address, and again on the fragment reads; with it the 16 lanes of every ds_read_b128 service group hit
+//    16 different 16-byte slots for any tap offset (checked exhaustively on the host, tests/test_host.py);
+//  * pixels outside the tensor are read from a zero page, so the staged image needs no separate clearing pass.
+//
+// Stages: with resident weights (all contraction chunks of all taps fit next to two patch buffers) a stage is one
+// (tile, chunk) and multiplies all taps; otherwise a stage is one (tile, chunk, tap group) whose weights are
+// double-buffered like the patches.
+#include "common.h"
+#include "kparams.h"
+
+namespace {
+
+static __device__ __align__(256) unsigned char g_zero_page[256];
+
+template <class TR>
+__device__ __forceinline__ v4f mma16v(const uint4& a, const uint4& b, v4f c);
+template <>
+__device__ __forceinline__ v4f mma16v<BF16>(const uint4& a, const uint4& b, v4f c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b), c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ v4f mma16v<F32>(const uint4& a, const uint4& b, v4f c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    return c;
+}
+
+__device__ __forceinline__ float row_sum16v(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+    return v;
+}
+
+template <int NFRAG>
+__device__ __forceinline__ int chan_of_row_v(int nf, int rr) {
+    if (NFRAG == 1) return rr;
+    return 32 * (nf >> 1) + 8 * (rr >> 2) + 4 * (nf & 1) + (rr & 3);
+}
+
+// 16 bytes per lane from global memory to LDS at lds_base + 16 * lane (lds_base wave-uniform)
+__device__ __forceinline__ void dma16(const char* gsrc, char* lds_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ int swz(int row) { return ((row >> 2) & 1) << 1; }
+
+// KS: 3 (3 x 3 taps, 18 x 18 patch) or 1 (one tap, 16 x 16).  TG: taps per stage; WRES: weights of all chunks and
+// taps stay in LDS (TG must then be the tap count).
+// all but the N youngest vector-memory operations of this wave have completed
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_c() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// KS: 3 (3 x 3 taps in patch order, 18 x 18 patch) or 1 (one tap, 16 x 16).
+// WRES: the weights of all chunks and taps stay in LDS and a stage is one (tile, chunk) with all taps; otherwise a
+// stage is one kernel row of one (tile, chunk), its weights in a ring of three buffers, and the loads of the stage
+// after next are issued at the top of a stage (one stage stays in flight across every barrier).
+// The loop body holds no integer division, no address arithmetic per fragment read (three per-lane bases per patch
+// buffer, everything else is an immediate offset) and every patch row fragment is read once per chunk and used by
+// up to three kernel rows: the MFMA share of the issued instructions decides the speed of this kernel.
+template <class TR, int NFRAG, int KS, bool WRES>
+__global__ __launch_bounds__(256, 2) void conv2d_dma_kernel(const IgemmParams p) {
+    constexpr int ESZ = TR::ESZ;
+    constexpr int KCE = 64 / ESZ;                  // contraction elements per 64-byte chunk row
+    constexpr int NT = NFRAG * 16;
+    constexpr int PD = KS == 3 ? 18 : 16;
+    constexpr int PP = PD * PD;
+    constexpr int NIP = (PP + 15) / 16;            // DMA wave-instructions per patch (16 pixel rows each)
+    constexpr int PBYTES = NIP * 1024;
+    constexpr int NUP = (NIP + 3) / 4;             // ... per wave
+    constexpr int NTAP = KS * KS;
+    constexpr int NG = WRES ? 1 : KS;              // stages per chunk
+    constexpr int TG = NTAP / NG;                  // taps per stage
+    constexpr int NWB = 3;                         // weight ring (streamed weights)
+    constexpr int WROWS = TG * NT;                 // weight rows per stage
+    constexpr int NIW = WROWS / 16;                // DMA wave-instructions per weight stage
+    constexpr int NUW = (NIW + 3) / 4;
+    constexpr int WBYTES = WROWS * 64;
+    constexpr int NROW = 4 + KS - 1;               // patch rows a wave touches
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    char* const smP = smem;                        // two patch buffers
+    char* const smW = smem + 2 * PBYTES;           // WRES: [chunk][tap][n] rows; else a ring of NWB stage buffers
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, g = lane >> 4;
+    const int H = p.id[1], W = p.id[2];
+    const int ntx = p.ntile[2], nty = p.ntile[1];
+    const int tile0 = blockIdx.x * p.tpw;
+    const int ntile_wg = p.tpw;                    // the launcher makes tpw divide the tiles of an image
+    const int n0 = blockIdx.y * NT;
+    const int slot = blockIdx.x % MI_NSLOT;
+    const int nkc = p.K / KCE;
+    const int nchunk = ntile_wg * nkc;
+    const int spb0 = p.in0_pitch * ESZ, spb1 = p.in1_pitch * ESZ;
+    const int nkc0 = min(nkc, p.in0_c / KCE);      // chunks that come from the first source
+
+    // ---- per-lane DMA constants ------------------------------------------------------------------------------------
+    // patch instruction i covers the 16 patch pixels 16 i .. 16 i + 15 (four lanes per pixel, one 16-byte slot each);
+    // slot j of pixel (py, px) receives source chunk j ^ swz(px)
+    int d_off0[NUP], d_off1[NUP], d_yx[NUP];
+#pragma unroll
+    for (int u = 0; u < NUP; ++u) {
+        const int pix = ((wave + 4 * u) % NIP) * 16 + (lane >> 2);
+        const int py = pix / PD, px = pix - py * PD;
+        const int cb = ((lane & 3) ^ swz(px)) * 16;
+        d_off0[u] = (py * W + px) * spb0 + cb;
+        d_off1[u] = (py * W + px) * spb1 + cb;
+        d_yx[u] = pix < PP ? ((py << 16) | px) : -1;
+    }
+    int w_off[NUW];
+#pragma unroll
+    for (int u = 0; u < NUW; ++u) {
+        const int row = ((wave + 4 * u) % NIW) * 16 + (lane >> 2);
+        const int tl = row / NT, r = row - tl * NT;
+        const int n = n0 + chan_of_row_v<NFRAG>(r >> 4, r & 15);
+        w_off[u] = ((tl * p.N + n) * p.K) * ESZ + ((lane & 3) ^ swz(row)) * 16;
+    }
+    const char* const zero = reinterpret_cast<const char*>(g_zero_page) + (lane & 3) * 16;
+
+    // position of the next chunk whose loads are issued: (image, tile row, tile column, chunk) and running counters
+    int q_img, q_ty, q_tx, q_kc = 0, q_chunk = 0, q_tg = 0;
+    {
+        const int tiles_img = ntx * nty;
+        q_img = tile0 / tiles_img;
+        const int r = tile0 - q_img * tiles_img;
+        q_ty = r / ntx; q_tx = r - q_ty * ntx;
+    }
+    int c_img = q_img, c_ty = q_ty, c_tx = q_tx;   // the same for the chunk being multiplied
+    const int img_wg = q_img;
+
+    auto issue_patch = [&]() {
+        const int iy0 = (q_ty << 4) + p.omin[1], ix0 = (q_tx << 4) + p.omin[2];
+        const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + PD <= H && ix0 + PD <= W;
+        const bool first = q_kc < nkc0;
+        const char* pb = first ? p.in0 + (((long long)q_img * H + iy0) * W + ix0) * spb0 + (p.in0_coff + q_kc * KCE) * ESZ
+                               : p.in1 + (((long long)q_img * H + iy0) * W + ix0) * spb1 + (p.in1_coff + (q_kc - nkc0) * KCE) * ESZ;
+        char* dst = smP + (q_chunk & 1) * PBYTES;
+#pragma unroll
+        for (int u = 0; u < NUP; ++u) {
+            const int i = (wave + 4 * u) % NIP;      // past the end: a harmless repeat, so every wave issues NUP loads
+            const int off = first ? d_off0[u] : d_off1[u];
+            if (interior) {
+                dma16(d_yx[u] >= 0 ? pb + off : zero, dst + i * 1024);
+            } else {
+                bool ok = d_yx[u] >= 0;
+                const int iy = iy0 + (d_yx[u] >> 16), ix = ix0 + (d_yx[u] & 0xffff);
+                ok = ok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                dma16(ok ? pb + off : zero, dst + i * 1024);
+            }
+        }
+    };
+    auto issue_weights = [&](int kc, int tg, char* dst) {
+        const char* wb = p.w + ((size_t)(tg * TG) * p.N * p.K + (size_t)kc * KCE) * ESZ;
+#pragma unroll
+        for (int u = 0; u < NUW; ++u) {
+            const int i = (wave + 4 * u) % NIW;      // repeats past the end, as for the patch
+            dma16(wb + w_off[u], dst + i * 1024);
+        }
+    };
+    // issues the loads of the next stage in line (nothing once every chunk has been issued) and advances the position
+    int q_ring = 0;
+    auto issue_next = [&]() {
+        if (q_chunk < nchunk) {
+            if (q_tg == 0) issue_patch();
+            if (!WRES) issue_weights(q_kc, q_tg, smW + q_ring * WBYTES);
+        }
+        if (!WRES) q_ring = q_ring == NWB - 1 ? 0 : q_ring + 1;
+        if (++q_tg == NG) {
+            q_tg = 0; ++q_chunk;
+            if (++q_kc == nkc) { q_kc = 0; if (++q_tx == ntx) { q_tx = 0; if (++q_ty == nty) { q_ty = 0; ++q_img; } } }
+        }
+    };
+
+    // ---- per-lane fragment read bases --------------------------------------------------------------------------------
+    int bx[KS];                                    // patch row 4 * wave, column lr + dx, chunk g (swizzled), buffer 0
+#pragma unroll
+    for (int dx = 0; dx < KS; ++dx) bx[dx] = ((wave * 4) * PD + lr + dx) * 64 + ((g ^ swz(lr + dx)) << 4);
+    const int w_lane = lr * 64 + ((g ^ swz(lr)) << 4);               // NT is a multiple of 16: the row's swizzle is lr's
+    const int rel0 = (wave * 4 * p.so) * p.od[2] + lr * p.so;
+    const int rel_step = p.so * p.od[2];
+
+    const bool do_stats = p.stats != nullptr;
+    float s1[NFRAG][4], s2[NFRAG][4];
+#pragma unroll
+    for (int nf = 0; nf < NFRAG; ++nf)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s1[nf][j] = 0.f; s2[nf][j] = 0.f; }
+
+    // ---- prologue ------------------------------------------------------------------------------------------------------
+    constexpr int LA = WRES ? 1 : 2;               // stages issued ahead
+    if (WRES)
+        for (int c = 0; c < nkc; ++c) issue_weights(c, 0, smW + c * WBYTES);
+#pragma unroll
+    for (int j = 0; j < LA; ++j) issue_next();
+
+    v4f acc[4][NFRAG];
+    int kc = 0, c_ring = 0;
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+        int cur[KS];
+        const int poff = (chunk & 1) * PBYTES;
+#pragma unroll
+        for (int dx = 0; dx < KS; ++dx) cur[dx] = bx[dx] + poff;
+        if (kc == 0) {
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+                for (int nf = 0; nf < NFRAG; ++nf) acc[mf][nf] = v4f{0.f, 0.f, 0.f, 0.f};
+        }
+        uint4 B[NROW][KS];                         // patch row fragments of this chunk (each read once)
+#pragma unroll
+        for (int tgc = 0; tgc < NG; ++tgc) {
+            // this wave's loads of the stage after this one may stay in flight; everything older must have landed
+            if (LA == 1) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else if (tgc == NG - 1) {            // the next stage opens a chunk: weights and a patch
+                if (chunk + 1 < nchunk) wait_vmcnt_c<NUW + NUP>(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                wait_vmcnt_c<NUW>();
+            }
+            __builtin_amdgcn_s_barrier();          // this stage has landed everywhere; the previous one has been consumed
+            asm volatile("" ::: "memory");
+            const char* wbuf = WRES ? smW + kc * WBYTES : smW + ((NG == NWB) ? tgc : c_ring) * WBYTES;
+            // rows this stage adds to the register window: all of them (whole chunk), or rows 0..3 / 4 / 5
+#pragma unroll
+            for (int r = 0; r < NROW; ++r) {
+                const bool load = WRES ? true : (tgc == 0 ? r < 4 : r == 3 + tgc);
+                if (load) {
+#pragma unroll
+                    for (int dx = 0; dx < KS; ++dx)
+                        B[r][dx] = *reinterpret_cast<const uint4*>(smem + cur[dx] + r * PD * 64);
+                }
+            }
+            uint4 afr[TG][NFRAG];
+#pragma unroll
+            for (int nf = 0; nf < NFRAG; ++nf) afr[0][nf] = *reinterpret_cast<const uint4*>(wbuf + (nf * 16) * 64 + w_lane);
+            // the fragment reads above are in flight while the loads of the stage LA ahead are issued
+            issue_next();
+#pragma unroll
+            for (int tl = 0; tl < TG; ++tl) {
+                const int t = tgc * TG + tl;       // tap in patch order: kernel row t / KS, column t % KS
+                const int dy = KS == 3 ? t / 3 : 0, dx = KS == 3 ? t % 3 : 0;
+                if (tl + 1 < TG) {
+#pragma unroll
+                    for (int nf = 0; nf < NFRAG; ++nf)
+                        afr[tl + 1][nf] = *reinterpret_cast<const uint4*>(wbuf + ((tl + 1) * NT + nf * 16) * 64 + w_lane);
+                }
+#pragma unroll
+                for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+                    for (int nf = 0; nf < NFRAG; ++nf) acc[mf][nf] = mma16v<TR>(afr[tl][nf], B[mf + dy][dx], acc[mf][nf]);
+            }
+            if (!WRES && NG != NWB) c_ring = c_ring == NWB - 1 ? 0 : c_ring + 1;
+        }
+
+        if (++kc == nkc) {
+            kc = 0;
+            // ---- tile epilogue ---------------------------------------------------------------------------------
+            const int by0 = c_ty << 4, bx0 = c_tx << 4;
+            const bool full = by0 + 16 <= p.bd[1] && bx0 + 16 <= p.bd[2];
+            const int base_pix = (c_img * p.od[1] + by0 * p.so + p.phase_off[0][1]) * p.od[2] + bx0 * p.so + p.phase_off[0][2];
+            if (++c_tx == ntx) { c_tx = 0; if (++c_ty == nty) { c_ty = 0; ++c_img; } }
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf) {
+                const bool valid = full || (by0 + wave * 4 + mf < p.bd[1] && bx0 + lr < p.bd[2]);
+                if (do_stats) {
+#pragma unroll
+                    for (int nf = 0; nf < NFRAG; ++nf)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float v = valid ? acc[mf][nf][j] : 0.f;
+                            s1[nf][j] += v; s2[nf][j] += v * v;
+                        }
+                }
+                if (valid) {
+                    const size_t op = (size_t)(base_pix + rel0 + mf * rel_step);
+                    if (NFRAG == 1) {
+                        const int ch = n0 + 4 * g;
+                        float v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = acc[mf][0][j];
+                        if (p.bias && ch >= p.bias_c0) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] += p.bias[ch - p.bias_c0 + j];
+                        }
+                        if (p.addend) {
+                            float a[4];
+                            load_n<TR, 4>(p.addend + (op * p.add_pitch + p.add_coff + ch) * ESZ, a);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] += a[j];
+                        }
+                        char* dst = ch < p.out0_c ? p.out + (op * p.out_pitch + p.out_coff + ch) * ESZ
+                                                  : p.out1 + (op * p.out1_pitch + p.out1_coff + ch - p.out0_c) * ESZ;
+                        store_n<TR, 4>(dst, v);
+                    } else {
+#pragma unroll
+                        for (int pf = 0; pf < NFRAG / 2; ++pf) {
+                            const int ch = n0 + 32 * pf + 8 * g;
+                            float v[8];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { v[j] = acc[mf][2 * pf][j]; v[4 + j] = acc[mf][2 * pf + 1][j]; }
+                            if (p.bias && ch >= p.bias_c0) {
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) v[j] += p.bias[ch - p.bias_c0 + j];
+                            }
+                            if (p.addend) {
+                                float a[8];
+                                load_n<TR, 8>(p.addend + (op * p.add_pitch + p.add_coff + ch) * ESZ, a);
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) v[j] += a[j];
+                            }
+                            char* dst = ch < p.out0_c ? p.out + (op * p.out_pitch + p.out_coff + ch) * ESZ
+                                                      : p.out1 + (op * p.out1_pitch + p.out1_coff + ch - p.out0_c) * ESZ;
+                            store_n<TR, 8>(dst, v);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    if (do_stats) {
+        // a workgroup's tiles lie in one image (tpw divides the tiles of an image)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        float* sst = reinterpret_cast<float*>(smem);  // [4 waves][NT][2]
+#pragma unroll
+        for (int nf = 0; nf < NFRAG; ++nf)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = row_sum16v(s1[nf][j]), bsum = row_sum16v(s2[nf][j]);
+                if (lr == 0) {
+                    const int cl = chan_of_row_v<NFRAG>(nf, 4 * g + j);
+                    sst[(wave * NT + cl) * 2] = a;
+                    sst[(wave * NT + cl) * 2 + 1] = bsum;
+                }
+            }
+        __syncthreads();
+        for (int i = tid; i < NT * 2; i += 256) {
+            const int ch = n0 + (i >> 1);
+            if (ch < p.nstat) {
+                const float v = ((sst[i] + sst[NT * 2 + i]) + sst[2 * NT * 2 + i]) + sst[3 * NT * 2 + i];
+                atomicAdd(&p.stats[(((size_t)img_wg * MI_NSLOT + slot) * p.stats_c + ch) * 2 + (i & 1)], (double)v);
+            }
+        }
+    }
+}
+
+template <class TR, int NFRAG, int KS, bool WRES>
+int launch_conv2d_t(const IgemmParams& pin, hipStream_t st) {
+    IgemmParams p = pin;
+    if (!p.out1) p.out0_c = p.N;
+    constexpr int NT = NFRAG * 16, PD = KS == 3 ? 18 : 16, NIP = (PD * PD + 15) / 16, NTAP = KS * KS;
+    const int nkc = p.K / (64 / TR::ESZ);
+    const size_t lds = (size_t)2 * NIP * 1024 + (WRES ? (size_t)nkc * NTAP * NT * 64 : (size_t)3 * (NTAP / KS) * NT * 64);
+    const int tiles_img = p.ntile[1] * p.ntile[2];
+    {
+        // tiles per workgroup: a divisor of the tiles of one image, aiming at about four workgroups per CU
+        const long long wgs1 = (long long)p.nb * tiles_img * (p.N / NT);
+        int want = (int)(wgs1 / 1024);
+        if (want > 16) want = 16;
+        if (want < 1) want = 1;
+        int tpw = 1;
+        for (int t = 1; t <= want; ++t) if (tiles_img % t == 0) tpw = t;
+        p.tpw = tpw;
+    }
+    auto kern = conv2d_dma_kernel<TR, NFRAG, KS, WRES>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { mi_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return -2; }
+    }
+    dim3 grid(p.nb * tiles_img / p.tpw, p.N / NT, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { mi_set_error(std::string("conv2d launch: ") + hipGetErrorString(e)); return -2; }
+    return 0;
+}
+
+}  // namespace
+
+// Geometry this file serves: 2-D tensor, 16 x 16 tile, unit gather stride, one phase with 9 taps on an 18 x 18 patch
+// or one tap on a 16 x 16 patch, contraction channels in whole 64-byte chunks from either source.
+bool conv2d_dma_applicable(int dtype, const IgemmParams& p) {
+    const int kce = 64 / (dtype ? 2 : 4);
+    if (p.id[0] != 1 || p.tlog[0] != 0 || p.tlog[1] != 4 || p.tlog[2] != 4 || p.pd[0] != 1) return false;
+    if (p.sa != 1 || p.so != 1 || p.nphase != 1 || p.ksplit > 1) return false;
+    const int ntaps = p.phase_start[1];
+    const bool k3 = ntaps == 9 && p.pd[1] == 18 && p.pd[2] == 18, k1 = ntaps == 1 && p.pd[1] == 16 && p.pd[2] == 16;
+    if (!k3 && !k1) return false;
+    for (int t = 0; t < ntaps; ++t)
+        if (p.tap_off[t] != (k3 ? (t / 3) * 18 + t % 3 : 0)) return false;      // taps in patch order (igemm_geometry sorts them)
+    if (p.K % kce || (p.in0_c < p.K && p.in0_c % kce) || p.N % 16) return false;
+    if ((long long)p.id[1] >= 65536 || (long long)p.id[2] >= 65536) return false;
+    return true;
+}
+
+int launch_conv2d_dma(int dtype, const IgemmParams& p, hipStream_t st) {
+    const int ntaps = p.phase_start[1];
+    const int nkc = p.K / (64 / (dtype ? 2 : 4));
+    const int nf = (p.N % 64 == 0) ? 4 : (p.N % 32 == 0) ? 2 : 1;
+    // resident weights when all chunks fit in 40 KiB next to the two patch buffers
+    const bool wres = (size_t)nkc * ntaps * nf * 16 * 64 <= 40 * 1024;
+#define CV_CASE(TRT, NF)                                                                       \
+    if (nf == NF) {                                                                            \
+        if (ntaps == 9) return wres ? launch_conv2d_t<TRT, NF, 3, true>(p, st) : launch_conv2d_t<TRT, NF, 3, false>(p, st); \
+        return wres ? launch_conv2d_t<TRT, NF, 1, true>(p, st) : launch_conv2d_t<TRT, NF, 1, false>(p, st); \
+    }
+    if (dtype) { CV_CASE(BF16, 4) CV_CASE(BF16, 2) CV_CASE(BF16, 1) }
+    else { CV_CASE(F32, 4) CV_CASE(F32, 2) CV_CASE(F32, 1) }
+#undef CV_CASE
+    mi_set_error("launch_conv2d_dma: no kernel variant");
+    return -1;
+}

@@ -176,6 +176,14 @@ inline bool igemm_geometry(const ConvShape& s, int dir, IgemmParams& p, int kidx
                        (t.off[i][2] - p.omin[2]);
         kidx[i] = t.kidx[i];
     }
+    // one-phase gathers: taps in ascending patch order (a data gradient mirrors the kernel, so its taps come out
+    // reversed); kernels with compile-time tap offsets rely on it, the weight packing follows kidx
+    if (t.nphase == 1)
+        for (int i = 1; i < t.n; ++i)
+            for (int j = i; j > 0 && p.tap_off[j - 1] > p.tap_off[j]; --j) {
+                const int a = p.tap_off[j]; p.tap_off[j] = p.tap_off[j - 1]; p.tap_off[j - 1] = a;
+                const int b = kidx[j]; kidx[j] = kidx[j - 1]; kidx[j - 1] = b;
+            }
     p.tapg = maxpt < 9 ? maxpt : 9;
     *ntaps = t.n;
     return true;

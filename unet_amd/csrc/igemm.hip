@@ -1182,7 +1182,18 @@ size_t igemm_lds_bytes(int dtype, const IgemmParams& p) {
     return igemm_lds_for(p, cps, nfrag);
 }
 
+bool conv2d_dma_enabled() {
+    static const bool on = !(getenv("MI_NO_CONV_DMA") && atoi(getenv("MI_NO_CONV_DMA")) != 0);
+    return on;
+}
+
 int launch_igemm(int dtype, const IgemmParams& p, hipStream_t st) {
+    if (conv2d_dma_enabled() && conv2d_dma_applicable(dtype, p)) {
+        MI_CHECK((long long)p.nb * p.od[0] * p.od[1] * p.od[2] < (1ll << 31) && (long long)p.nb * p.id[0] * p.id[1] * p.id[2] < (1ll << 31),
+                 "tensor has too many pixels for 32-bit pixel indices");
+        MI_CHECK(!p.out1 || (p.out0_c % 16 == 0 && p.out0_c > 0 && p.out0_c < p.N), "first-destination channel count must be a multiple of 16");
+        return launch_conv2d_dma(dtype, p, st);
+    }
     int cps, nfrag;
     igemm_config(dtype, p, &cps, &nfrag);
     const int esz = dtype ? 2 : 4;
