@@ -77,7 +77,6 @@ static int run_igemm(const mi_conv_desc* d, int dir, const mi_tensor* in, const 
     p.out = (char*)out->ptr; p.out_pitch = out->pitch; p.out_coff = out->coff;
     if (addend && addend->ptr) { p.addend = (const char*)addend->ptr; p.add_pitch = addend->pitch; p.add_coff = addend->coff; }
     if (stats) { p.stats = stats; p.stats_c = p.N; p.nstat = p.N; }
-    if (const char* e = getenv("MI_DBG_PTR")) p.kpart = (float*)strtoull(e, nullptr, 0);   // TEMP diagnosis
     return launch_igemm(d->dtype, p, (hipStream_t)stream);
 }
 
