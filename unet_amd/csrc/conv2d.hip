@@ -54,8 +54,13 @@ __device__ __forceinline__ int chan_of_row_v(int nf, int rr) {
 
 // 16 bytes per lane from global memory to LDS at lds_base + 16 * lane (lds_base wave-uniform)
 __device__ __forceinline__ void dma16(const char* gsrc, char* lds_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+    // Inline assembly on purpose: hipcc drains every outstanding LDS-DMA it knows of (s_waitcnt vmcnt(0)) in front
+    // of the next LDS read, which would undo the prefetch; loads it does not know of are waited for by the counted
+    // s_waitcnt vmcnt(N) of the stage loops alone.  M0 holds the wave-uniform LDS destination and is restored.
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
 
 __device__ __forceinline__ int swz(int row) { return ((row >> 2) & 1) << 1; }

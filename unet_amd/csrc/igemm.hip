@@ -1289,6 +1289,14 @@ int launch_wgrad(int dtype, const WgradParams& p, hipStream_t st) {
     MI_CHECK(wgrad_lds_for(dtype, p, 16 * ff * wf, 16 * sf * wsn) <= 160 * 1024, "LDS images do not fit");
     const int nt = p.ntaps_total / p.ntapg;
     MI_CHECK(nt == 9 || nt == 1, "taps per group must be 9 or 1");
+    {
+        static const bool dma = !(getenv("MI_NO_WGRAD_DMA") && atoi(getenv("MI_NO_WGRAD_DMA")) != 0);
+        if (dma) {
+            WgradParams q = p;
+            const int r = launch_wgrad_dma(dtype, q, ff, sf, wf, wsn, st);
+            if (r <= 0) return r;
+        }
+    }
 #define WG_CASE(TRT, NTT, A, B, C, D) \
     if (nt == NTT && ff == A && sf == B && wf == C && wsn == D) return launch_wgrad_t<TRT, NTT, A, B, C, D>(p, st);
 #define WG_ALL(TRT, NTT)                                                                  \
