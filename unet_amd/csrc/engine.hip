@@ -335,7 +335,7 @@ struct Builder {
         p.nb = u.nb; p.npix = (int)u.rp[res]; p.c = c; p.eps = 1e-5f; p.layer = (unsigned)lid;
         const int esz = dt ? 2 : 4;
         s.kernel = c == 1 ? "norm1_bwd_kernels" : (dt ? "norm_bwd_kernels<BF16>" : "norm_bwd_kernels<F32>");
-        s.work = (double)u.nb * u.rp[res] * c * esz * 5.0;
+        s.work = (double)u.nb * u.rp[res] * c * esz * 3.0;   // algorithmic: x and dy read, dx written (the kernels read x and dy twice)
         add_scalar_reduce(da, nda, alpha);
     }
 
