@@ -25,6 +25,10 @@ def label(name: str) -> str:
         return f"igemm_kernel<{tr},{rest[0]},{rest[1]}>"
     if kern == "wgrad_kernel":
         return f"wgrad_kernel<{tr},{','.join(rest)}>"
+    if kern == "wgrad_dma_kernel":           # same step label as the register-staged kernel it stands in for
+        return f"wgrad_kernel<{tr},{','.join(rest[:5])}>"
+    if kern == "conv2d_dma_kernel":
+        return f"conv2d_dma_kernel<{tr},{rest[0]}>"
     return f"{kern}<{tr}>"
 
 

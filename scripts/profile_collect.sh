@@ -1,7 +1,9 @@
 #!/bin/bash
 # GPU-side collection for profiles/: usage scripts/profile_collect.sh STAGE   (outputs under gpurun_out/prof/)
 #   pmc   : FETCH_SIZE and WRITE_SIZE passes (one counter per pass)
+#   sq    : one pass of eight SQ counters on a single stream
 #   trace : kernel traces (single stream and production schedule) and bench.py's own tables
+#   alt   : the secondary workloads (3-D training, sliding-window inference): kernel stats, bench JSON, per-layer table
 set -o pipefail
 STAGE=${1:-trace}
 OUT=gpurun_out/prof
@@ -15,6 +17,21 @@ if [ "$STAGE" = pmc ]; then
     rm -rf $OUT/pmc_$c
   done
   ls -la $OUT
+elif [ "$STAGE" = sq ]; then
+  rm -rf $OUT/sq
+  MI_NO_SIDE_STREAM=1 timeout -s KILL 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES -d $OUT/sq -o pmc --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $OUT/sq.log 2>&1 || exit 1
+  cp "$(find $OUT/sq -name '*counter_collection.csv' | head -1)" $OUT/pmc_sq.csv || exit 1
+  rm -rf $OUT/sq
+elif [ "$STAGE" = alt ]; then
+  for w in 3d infer; do
+    if [ $w = 3d ]; then ARGS="--dims 3 --size 96 --batch 4"; else ARGS="--mode infer"; fi
+    rm -rf $OUT/a_$w
+    timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $OUT/a_$w -o r --output-format csv -- python3 bench.py $ARGS --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing > $OUT/trace_$w.log 2>&1 || exit 1
+    cp "$(find $OUT/a_$w -name '*kernel_stats.csv' | head -1)" $OUT/kernel_stats_$w.csv || exit 1
+    rm -rf $OUT/a_$w
+    BENCH_LAYERS=1 timeout -k 10 300 python bench.py $ARGS --no-cpu-baseline > $OUT/bench_$w.json 2> $OUT/per_layer_$w.txt || exit 1
+    cat $OUT/bench_$w.json
+  done
 else
   rm -rf $OUT/t1 $OUT/t2
   MI_NO_SIDE_STREAM=1 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $OUT/t1 -o r --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing > $OUT/trace1.log 2>&1 || exit 1
