@@ -187,11 +187,11 @@ def _max_ways(addr_of_lane):
     return worst
 
 
-@pytest.mark.parametrize("pd", [16, 18])
+@pytest.mark.parametrize("pd", [16, 17, 18])
 def test_conv2d_patch_and_weight_fragment_reads_are_bank_conflict_free(pd):
     # patch fragment of lane (lr, g): pixel row `row`, column lr + dx, 16-byte chunk g of the 64-byte pixel row,
     # stored in slot g ^ swz(column); weight fragment: row lr of a 16-row block, slot g ^ swz(lr)
-    ks = 3 if pd == 18 else 1
+    ks = {16: 1, 17: 2, 18: 3}[pd]       # tap columns read from a patch of that width
     for row in range(pd):
         for dx in range(ks):
             def addr(lane, row=row, dx=dx):

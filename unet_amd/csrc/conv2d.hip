@@ -65,6 +65,104 @@ __device__ __forceinline__ void dma16(const char* gsrc, char* lds_base) {
 
 __device__ __forceinline__ int swz(int row) { return ((row >> 2) & 1) << 1; }
 
+
+// Epilogue of one 16 x 16 base-pixel tile: the wave's four accumulator rows (base rows 4 * wave + mf, column lr) get
+// bias / addend, go to one of the two destinations, and feed the running norm statistics.  Output pixel of base
+// pixel (y, x): base_pix + rel0 + mf * rel_step (the caller folds in image, tile origin, output stride and phase).
+template <class TR, int NFRAG>
+__device__ __forceinline__ void tile_epilogue(const IgemmParams& p, const v4f (&acc)[4][NFRAG], int base_pix, int rel0, int rel_step,
+                                              int by0, int bx0, int wave, int lr, int g, int n0, bool do_stats,
+                                              float (&s1)[NFRAG][4], float (&s2)[NFRAG][4]) {
+    constexpr int ESZ = TR::ESZ;
+    const bool full = by0 + 16 <= p.bd[1] && bx0 + 16 <= p.bd[2];
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf) {
+        const bool valid = full || (by0 + wave * 4 + mf < p.bd[1] && bx0 + lr < p.bd[2]);
+        if (do_stats) {
+#pragma unroll
+            for (int nf = 0; nf < NFRAG; ++nf)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = valid ? acc[mf][nf][j] : 0.f;
+                    s1[nf][j] += v; s2[nf][j] += v * v;
+                }
+        }
+        if (valid) {
+            const size_t op = (size_t)(base_pix + rel0 + mf * rel_step);
+            if (NFRAG == 1) {
+                const int ch = n0 + 4 * g;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[mf][0][j];
+                if (p.bias && ch >= p.bias_c0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += p.bias[ch - p.bias_c0 + j];
+                }
+                if (p.addend) {
+                    float a[4];
+                    load_n<TR, 4>(p.addend + (op * p.add_pitch + p.add_coff + ch) * ESZ, a);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += a[j];
+                }
+                char* dst = ch < p.out0_c ? p.out + (op * p.out_pitch + p.out_coff + ch) * ESZ
+                                          : p.out1 + (op * p.out1_pitch + p.out1_coff + ch - p.out0_c) * ESZ;
+                store_n<TR, 4>(dst, v);
+            } else {
+#pragma unroll
+                for (int pf = 0; pf < NFRAG / 2; ++pf) {
+                    const int ch = n0 + 32 * pf + 8 * g;
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[j] = acc[mf][2 * pf][j]; v[4 + j] = acc[mf][2 * pf + 1][j]; }
+                    if (p.bias && ch >= p.bias_c0) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] += p.bias[ch - p.bias_c0 + j];
+                    }
+                    if (p.addend) {
+                        float a[8];
+                        load_n<TR, 8>(p.addend + (op * p.add_pitch + p.add_coff + ch) * ESZ, a);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] += a[j];
+                    }
+                    char* dst = ch < p.out0_c ? p.out + (op * p.out_pitch + p.out_coff + ch) * ESZ
+                                              : p.out1 + (op * p.out1_pitch + p.out1_coff + ch - p.out0_c) * ESZ;
+                    store_n<TR, 8>(dst, v);
+                }
+            }
+        }
+    }
+}
+
+// Adds the workgroup's statistics partials to the fp64 accumulators of image img_wg (all tiles of a workgroup lie in
+// one image).  smem is reused as [4 waves][NT][2] floats: every LDS-DMA must have landed and been consumed.
+template <int NFRAG>
+__device__ __forceinline__ void flush_stats(const IgemmParams& p, char* smem, const float (&s1)[NFRAG][4], const float (&s2)[NFRAG][4],
+                                            int wave, int lr, int g, int n0, int img_wg, int slot) {
+    constexpr int NT = NFRAG * 16;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float* sst = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int nf = 0; nf < NFRAG; ++nf)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a = row_sum16v(s1[nf][j]), bsum = row_sum16v(s2[nf][j]);
+            if (lr == 0) {
+                const int cl = chan_of_row_v<NFRAG>(nf, 4 * g + j);
+                sst[(wave * NT + cl) * 2] = a;
+                sst[(wave * NT + cl) * 2 + 1] = bsum;
+            }
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NT * 2; i += 256) {
+        const int ch = n0 + (i >> 1);
+        if (ch < p.nstat) {
+            const float v = ((sst[i] + sst[NT * 2 + i]) + sst[2 * NT * 2 + i]) + sst[3 * NT * 2 + i];
+            atomicAdd(&p.stats[(((size_t)img_wg * MI_NSLOT + slot) * p.stats_c + ch) * 2 + (i & 1)], (double)v);
+        }
+    }
+}
+
 // KS: 3 (3 x 3 taps, 18 x 18 patch) or 1 (one tap, 16 x 16).  TG: taps per stage; WRES: weights of all chunks and
 // taps stay in LDS (TG must then be the tap count).
 // all but the N youngest vector-memory operations of this wave have completed
@@ -280,93 +378,396 @@ __global__ __launch_bounds__(256, 2) void conv2d_dma_kernel(const IgemmParams p)
             kc = 0;
             // ---- tile epilogue ---------------------------------------------------------------------------------
             const int by0 = c_ty << 4, bx0 = c_tx << 4;
-            const bool full = by0 + 16 <= p.bd[1] && bx0 + 16 <= p.bd[2];
             const int base_pix = (c_img * p.od[1] + by0 * p.so + p.phase_off[0][1]) * p.od[2] + bx0 * p.so + p.phase_off[0][2];
             if (++c_tx == ntx) { c_tx = 0; if (++c_ty == nty) { c_ty = 0; ++c_img; } }
-#pragma unroll
-            for (int mf = 0; mf < 4; ++mf) {
-                const bool valid = full || (by0 + wave * 4 + mf < p.bd[1] && bx0 + lr < p.bd[2]);
-                if (do_stats) {
-#pragma unroll
-                    for (int nf = 0; nf < NFRAG; ++nf)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float v = valid ? acc[mf][nf][j] : 0.f;
-                            s1[nf][j] += v; s2[nf][j] += v * v;
-                        }
-                }
-                if (valid) {
-                    const size_t op = (size_t)(base_pix + rel0 + mf * rel_step);
-                    if (NFRAG == 1) {
-                        const int ch = n0 + 4 * g;
-                        float v[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = acc[mf][0][j];
-                        if (p.bias && ch >= p.bias_c0) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] += p.bias[ch - p.bias_c0 + j];
-                        }
-                        if (p.addend) {
-                            float a[4];
-                            load_n<TR, 4>(p.addend + (op * p.add_pitch + p.add_coff + ch) * ESZ, a);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] += a[j];
-                        }
-                        char* dst = ch < p.out0_c ? p.out + (op * p.out_pitch + p.out_coff + ch) * ESZ
-                                                  : p.out1 + (op * p.out1_pitch + p.out1_coff + ch - p.out0_c) * ESZ;
-                        store_n<TR, 4>(dst, v);
-                    } else {
-#pragma unroll
-                        for (int pf = 0; pf < NFRAG / 2; ++pf) {
-                            const int ch = n0 + 32 * pf + 8 * g;
-                            float v[8];
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) { v[j] = acc[mf][2 * pf][j]; v[4 + j] = acc[mf][2 * pf + 1][j]; }
-                            if (p.bias && ch >= p.bias_c0) {
-#pragma unroll
-                                for (int j = 0; j < 8; ++j) v[j] += p.bias[ch - p.bias_c0 + j];
-                            }
-                            if (p.addend) {
-                                float a[8];
-                                load_n<TR, 8>(p.addend + (op * p.add_pitch + p.add_coff + ch) * ESZ, a);
-#pragma unroll
-                                for (int j = 0; j < 8; ++j) v[j] += a[j];
-                            }
-                            char* dst = ch < p.out0_c ? p.out + (op * p.out_pitch + p.out_coff + ch) * ESZ
-                                                      : p.out1 + (op * p.out1_pitch + p.out1_coff + ch - p.out0_c) * ESZ;
-                            store_n<TR, 8>(dst, v);
-                        }
-                    }
-                }
-            }
+            tile_epilogue<TR, NFRAG>(p, acc, base_pix, rel0, rel_step, by0, bx0, wave, lr, g, n0, do_stats, s1, s2);
         }
     }
 
-    if (do_stats) {
-        // a workgroup's tiles lie in one image (tpw divides the tiles of an image)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        float* sst = reinterpret_cast<float*>(smem);  // [4 waves][NT][2]
+    if (do_stats) flush_stats<NFRAG>(p, smem, s1, s2, wave, lr, g, n0, img_wg, slot);
+}
+
+// ---- stride-2 scatter ("phase") form: transposed convolution k3 s2, and the data gradient of a stride-2 convolution --
+// Base pixel (y, x) of the gathered tensor produces the four output pixels (2y + a, 2x + b); phase (a, b) sums
+// 1, 2, 2 or 4 taps at gather offsets in {0, 1}^2.  One stage = one (tile, chunk): a 17 x 17 patch (unit gather stride)
+// and the nine tap weight tiles of the chunk, both double-buffered, loads of the next chunk issued under the MFMA loop.
+// A patch fragment is read once per chunk (5 rows x 2 columns per wave) and feeds all phases that touch it.
+// tap slots in the order the host emits them: phase (0,0): (0,0); (0,1): (0,1) (0,0); (1,0): (1,0) (0,0);
+// (1,1): (1,1) (1,0) (0,1) (0,0)    [(row offset, column offset)]
+__host__ __device__ constexpr int ph_of_tap(int t) { return t < 1 ? 0 : t < 3 ? 1 : t < 5 ? 2 : 3; }
+__host__ __device__ constexpr int ph_dy(int t) { return (t == 3 || t == 5 || t == 6) ? 1 : 0; }
+__host__ __device__ constexpr int ph_dx(int t) { return (t == 1 || t == 5 || t == 7) ? 1 : 0; }
+
+template <class TR, int NFRAG>
+__global__ __launch_bounds__(256, 2) void conv2d_phase_kernel(const IgemmParams p) {
+    constexpr int ESZ = TR::ESZ;
+    constexpr int KCE = 64 / ESZ;
+    constexpr int NT = NFRAG * 16;
+    constexpr int PD = 17, PP = PD * PD;
+    constexpr int NIP = (PP + 15) / 16;            // 19 DMA wave-instructions per patch
+    constexpr int PBYTES = NIP * 1024;
+    constexpr int NUP = (NIP + 3) / 4;
+    constexpr int NTAP = 9;
+    constexpr int WROWS = NTAP * NT;
+    constexpr int NIW = WROWS / 16;
+    constexpr int NUW = (NIW + 3) / 4;
+    constexpr int WBYTES = WROWS * 64;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    char* const smP = smem;                        // two patch buffers
+    char* const smW = smem + 2 * PBYTES;           // two weight buffers [tap][n] rows
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, g = lane >> 4;
+    const int H = p.id[1], W = p.id[2];
+    const int ntx = p.ntile[2], nty = p.ntile[1];
+    const int tile0 = blockIdx.x * p.tpw;
+    const int n0 = blockIdx.y * NT;
+    const int slot = blockIdx.x % MI_NSLOT;
+    const int nkc = p.K / KCE;
+    const int nchunk = p.tpw * nkc;
+    const int spb0 = p.in0_pitch * ESZ, spb1 = p.in1_pitch * ESZ;
+    const int nkc0 = min(nkc, p.in0_c / KCE);
+
+    int d_off0[NUP], d_off1[NUP], d_yx[NUP];
 #pragma unroll
-        for (int nf = 0; nf < NFRAG; ++nf)
+    for (int u = 0; u < NUP; ++u) {
+        const int pix = ((wave + 4 * u) % NIP) * 16 + (lane >> 2);
+        const int py = pix / PD, px = pix - py * PD;
+        const int cb = ((lane & 3) ^ swz(px)) * 16;
+        d_off0[u] = (py * W + px) * spb0 + cb;
+        d_off1[u] = (py * W + px) * spb1 + cb;
+        d_yx[u] = pix < PP ? ((py << 16) | px) : -1;
+    }
+    int w_off[NUW];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float a = row_sum16v(s1[nf][j]), bsum = row_sum16v(s2[nf][j]);
-                if (lr == 0) {
-                    const int cl = chan_of_row_v<NFRAG>(nf, 4 * g + j);
-                    sst[(wave * NT + cl) * 2] = a;
-                    sst[(wave * NT + cl) * 2 + 1] = bsum;
-                }
+    for (int u = 0; u < NUW; ++u) {
+        const int row = ((wave + 4 * u) % NIW) * 16 + (lane >> 2);
+        const int tl = row / NT, r = row - tl * NT;
+        const int n = n0 + chan_of_row_v<NFRAG>(r >> 4, r & 15);
+        w_off[u] = ((tl * p.N + n) * p.K) * ESZ + ((lane & 3) ^ swz(row)) * 16;
+    }
+    const char* const zero = reinterpret_cast<const char*>(g_zero_page) + (lane & 3) * 16;
+
+    int q_img, q_ty, q_tx, q_kc = 0, q_chunk = 0;
+    {
+        const int tiles_img = ntx * nty;
+        q_img = tile0 / tiles_img;
+        const int r = tile0 - q_img * tiles_img;
+        q_ty = r / ntx; q_tx = r - q_ty * ntx;
+    }
+    int c_img = q_img, c_ty = q_ty, c_tx = q_tx;
+    const int img_wg = q_img;
+
+    auto issue_next = [&]() {
+        if (q_chunk < nchunk) {
+            const int iy0 = q_ty << 4, ix0 = q_tx << 4;             // gather offsets start at 0
+            const bool interior = iy0 + PD <= H && ix0 + PD <= W;
+            const bool first = q_kc < nkc0;
+            const char* pb = first ? p.in0 + (((long long)q_img * H + iy0) * W + ix0) * spb0 + (p.in0_coff + q_kc * KCE) * ESZ
+                                   : p.in1 + (((long long)q_img * H + iy0) * W + ix0) * spb1 + (p.in1_coff + (q_kc - nkc0) * KCE) * ESZ;
+            char* dst = smP + (q_chunk & 1) * PBYTES;
+#pragma unroll
+            for (int u = 0; u < NUP; ++u) {
+                const int i = (wave + 4 * u) % NIP;
+                const int off = first ? d_off0[u] : d_off1[u];
+                bool ok = d_yx[u] >= 0;
+                if (!interior) ok = ok && iy0 + (d_yx[u] >> 16) < H && ix0 + (d_yx[u] & 0xffff) < W;
+                dma16(ok ? pb + off : zero, dst + i * 1024);
             }
-        __syncthreads();
-        for (int i = tid; i < NT * 2; i += 256) {
-            const int ch = n0 + (i >> 1);
-            if (ch < p.nstat) {
-                const float v = ((sst[i] + sst[NT * 2 + i]) + sst[2 * NT * 2 + i]) + sst[3 * NT * 2 + i];
-                atomicAdd(&p.stats[(((size_t)img_wg * MI_NSLOT + slot) * p.stats_c + ch) * 2 + (i & 1)], (double)v);
+            const char* wb = p.w + (size_t)q_kc * KCE * ESZ;
+            char* wdst = smW + (q_chunk & 1) * WBYTES;
+#pragma unroll
+            for (int u = 0; u < NUW; ++u) {
+                const int i = (wave + 4 * u) % NIW;
+                dma16(wb + w_off[u], wdst + i * 1024);
             }
         }
+        ++q_chunk;
+        if (++q_kc == nkc) { q_kc = 0; if (++q_tx == ntx) { q_tx = 0; if (++q_ty == nty) { q_ty = 0; ++q_img; } } }
+    };
+
+    int bx[2];
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) bx[dx] = ((wave * 4) * PD + lr + dx) * 64 + ((g ^ swz(lr + dx)) << 4);
+    const int w_lane = lr * 64 + ((g ^ swz(lr)) << 4);
+    const int rel0 = (wave * 4 * 2) * p.od[2] + lr * 2;
+    const int rel_step = 2 * p.od[2];
+
+    const bool do_stats = p.stats != nullptr;
+    float s1[NFRAG][4], s2[NFRAG][4];
+#pragma unroll
+    for (int nf = 0; nf < NFRAG; ++nf)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s1[nf][j] = 0.f; s2[nf][j] = 0.f; }
+
+    issue_next();
+    v4f acc[4][4][NFRAG];                          // [phase][base row of the wave][channel fragment]
+    int kc = 0;
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+        const int poff = (chunk & 1) * PBYTES;
+        const char* wbuf = smW + (chunk & 1) * WBYTES;
+        if (kc == 0) {
+#pragma unroll
+            for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+                for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+                    for (int nf = 0; nf < NFRAG; ++nf) acc[ph][mf][nf] = v4f{0.f, 0.f, 0.f, 0.f};
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();              // this chunk has landed everywhere; the other buffers are free
+        asm volatile("" ::: "memory");
+        uint4 B[5][2];
+#pragma unroll
+        for (int r = 0; r < 5; ++r)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) B[r][dx] = *reinterpret_cast<const uint4*>(smem + poff + bx[dx] + r * PD * 64);
+        uint4 afr[2][NFRAG];
+#pragma unroll
+        for (int nf = 0; nf < NFRAG; ++nf) afr[0][nf] = *reinterpret_cast<const uint4*>(wbuf + (nf * 16) * 64 + w_lane);
+        issue_next();
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) {
+            if (t + 1 < NTAP) {
+#pragma unroll
+                for (int nf = 0; nf < NFRAG; ++nf)
+                    afr[(t + 1) & 1][nf] = *reinterpret_cast<const uint4*>(wbuf + ((t + 1) * NT + nf * 16) * 64 + w_lane);
+            }
+            constexpr int dummy = 0; (void)dummy;
+            const int ph = ph_of_tap(t), dy = ph_dy(t), dx = ph_dx(t);
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+                for (int nf = 0; nf < NFRAG; ++nf) acc[ph][mf][nf] = mma16v<TR>(afr[t & 1][nf], B[mf + dy][dx], acc[ph][mf][nf]);
+        }
+        if (++kc == nkc) {
+            kc = 0;
+            const int by0 = c_ty << 4, bx0 = c_tx << 4;
+#pragma unroll
+            for (int ph = 0; ph < 4; ++ph) {
+                const int base_pix = (c_img * p.od[1] + by0 * 2 + (ph >> 1)) * p.od[2] + bx0 * 2 + (ph & 1);
+                tile_epilogue<TR, NFRAG>(p, acc[ph], base_pix, rel0, rel_step, by0, bx0, wave, lr, g, n0, do_stats, s1, s2);
+            }
+            if (++c_tx == ntx) { c_tx = 0; if (++c_ty == nty) { c_ty = 0; ++c_img; } }
+        }
     }
+    if (do_stats) flush_stats<NFRAG>(p, smem, s1, s2, wave, lr, g, n0, img_wg, slot);
+}
+
+// tiles per workgroup: a divisor of the tiles of one image, aiming at about four workgroups per CU
+static int tiles_per_wg(const IgemmParams& p, int NT) {
+    const int tiles_img = p.ntile[1] * p.ntile[2];
+    const long long wgs1 = (long long)p.nb * tiles_img * (p.N / NT);
+    int want = (int)(wgs1 / 1024);
+    if (want > 16) want = 16;
+    if (want < 1) want = 1;
+    int tpw = 1;
+    for (int t = 1; t <= want; ++t) if (tiles_img % t == 0) tpw = t;
+    return tpw;
+}
+
+template <class TR, int NFRAG>
+int launch_conv2d_phase_t(const IgemmParams& pin, hipStream_t st) {
+    IgemmParams p = pin;
+    if (!p.out1) p.out0_c = p.N;
+    constexpr int NT = NFRAG * 16;
+    const size_t lds = (size_t)2 * 19 * 1024 + (size_t)2 * 9 * NT * 64;
+    p.tpw = tiles_per_wg(p, NT);
+    auto kern = conv2d_phase_kernel<TR, NFRAG>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { mi_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return -2; }
+    }
+    dim3 grid(p.nb * p.ntile[1] * p.ntile[2] / p.tpw, p.N / NT, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { mi_set_error(std::string("conv2d phase launch: ") + hipGetErrorString(e)); return -2; }
+    return 0;
+}
+
+// ---- stride-2 gather form: stride-2 convolution k3 p1, and the data gradient of the k3 s2 transposed convolution ------
+// Output pixel (y, x) gathers input pixels (2y - 1 + ky, 2x - 1 + kx).  A tap reads one of the four polyphase
+// components of the input: component (ry, rx) = pixels (2i - ry, 2j - rx), and inside a component the gather has unit
+// stride, so the fragment reads look like those of the unit-stride kernel.  One stage = one (tile, chunk, component):
+// a 17 x 17 component patch with 1, 2, 2 or 4 taps (ky = 1 lives in ry = 0 at row offset 0; ky = 0 and 2 in ry = 1 at
+// row offsets 0 and 1; the same along x).  Patches are double-buffered, the weights of all chunks stay in LDS.
+template <class TR, int NFRAG>
+__global__ __launch_bounds__(256, 2) void conv2d_s2_kernel(const IgemmParams p) {
+    constexpr int ESZ = TR::ESZ;
+    constexpr int KCE = 64 / ESZ;
+    constexpr int NT = NFRAG * 16;
+    constexpr int PD = 17, PP = PD * PD;
+    constexpr int NIP = (PP + 15) / 16;
+    constexpr int PBYTES = NIP * 1024;
+    constexpr int NUP = (NIP + 3) / 4;
+    constexpr int NTAP = 9;
+    constexpr int WROWS = NTAP * NT;
+    constexpr int NIW = WROWS / 16;
+    constexpr int NUW = (NIW + 3) / 4;
+    constexpr int WBYTES = WROWS * 64;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    char* const smP = smem;
+    char* const smW = smem + 2 * PBYTES;           // [chunk][tap][n] rows
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, g = lane >> 4;
+    const int H = p.id[1], W = p.id[2];
+    const int ntx = p.ntile[2], nty = p.ntile[1];
+    const int tile0 = blockIdx.x * p.tpw;
+    const int n0 = blockIdx.y * NT;
+    const int slot = blockIdx.x % MI_NSLOT;
+    const int nkc = p.K / KCE;
+    const int nstage = p.tpw * nkc * 4;
+    const int spb0 = p.in0_pitch * ESZ, spb1 = p.in1_pitch * ESZ;
+    const int nkc0 = min(nkc, p.in0_c / KCE);
+
+    int d_off0[NUP], d_off1[NUP], d_yx[NUP];       // component patch pixel (py, px) sits 2 py rows and 2 px columns from the origin
+#pragma unroll
+    for (int u = 0; u < NUP; ++u) {
+        const int pix = ((wave + 4 * u) % NIP) * 16 + (lane >> 2);
+        const int py = pix / PD, px = pix - py * PD;
+        const int cb = ((lane & 3) ^ swz(px)) * 16;
+        d_off0[u] = (2 * py * W + 2 * px) * spb0 + cb;
+        d_off1[u] = (2 * py * W + 2 * px) * spb1 + cb;
+        d_yx[u] = pix < PP ? ((py << 16) | px) : -1;
+    }
+    const char* const zero = reinterpret_cast<const char*>(g_zero_page) + (lane & 3) * 16;
+
+    int q_img, q_ty, q_tx, q_kc = 0, q_c = 0, q_stage = 0;
+    {
+        const int tiles_img = ntx * nty;
+        q_img = tile0 / tiles_img;
+        const int r = tile0 - q_img * tiles_img;
+        q_ty = r / ntx; q_tx = r - q_ty * ntx;
+    }
+    int c_img = q_img, c_ty = q_ty, c_tx = q_tx;
+    const int img_wg = q_img;
+
+    auto issue_next = [&]() {
+        if (q_stage < nstage) {
+            const int ry = q_c >> 1, rx = q_c & 1;
+            const int iy0 = (q_ty << 5) - ry, ix0 = (q_tx << 5) - rx;
+            const bool first = q_kc < nkc0;
+            const char* pb = first ? p.in0 + (((long long)q_img * H + iy0) * W + ix0) * spb0 + (p.in0_coff + q_kc * KCE) * ESZ
+                                   : p.in1 + (((long long)q_img * H + iy0) * W + ix0) * spb1 + (p.in1_coff + (q_kc - nkc0) * KCE) * ESZ;
+            char* dst = smP + (q_stage & 1) * PBYTES;
+#pragma unroll
+            for (int u = 0; u < NUP; ++u) {
+                const int i = (wave + 4 * u) % NIP;
+                const int off = first ? d_off0[u] : d_off1[u];
+                const int iy = iy0 + 2 * (d_yx[u] >> 16), ix = ix0 + 2 * (d_yx[u] & 0xffff);
+                const bool ok = d_yx[u] >= 0 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                dma16(ok ? pb + off : zero, dst + i * 1024);
+            }
+        }
+        ++q_stage;
+        if (++q_c == 4) {
+            q_c = 0;
+            if (++q_kc == nkc) { q_kc = 0; if (++q_tx == ntx) { q_tx = 0; if (++q_ty == nty) { q_ty = 0; ++q_img; } } }
+        }
+    };
+
+    // resident weights: every chunk's [tap][n] rows
+    for (int c = 0; c < nkc; ++c) {
+#pragma unroll
+        for (int u = 0; u < NUW; ++u) {
+            const int i = (wave + 4 * u) % NIW;
+            const int row = i * 16 + (lane >> 2);
+            const int tl = row / NT, r = row - tl * NT;
+            const int n = n0 + chan_of_row_v<NFRAG>(r >> 4, r & 15);
+            dma16(p.w + ((size_t)(tl * p.N + n) * p.K + (size_t)c * KCE) * ESZ + ((lane & 3) ^ swz(row)) * 16, smW + c * WBYTES + i * 1024);
+        }
+    }
+
+    int bx[2];
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) bx[dx] = ((wave * 4) * PD + lr + dx) * 64 + ((g ^ swz(lr + dx)) << 4);
+    const int w_lane = lr * 64 + ((g ^ swz(lr)) << 4);
+    const int rel0 = (wave * 4) * p.od[2] + lr;
+    const int rel_step = p.od[2];
+
+    const bool do_stats = p.stats != nullptr;
+    float s1[NFRAG][4], s2[NFRAG][4];
+#pragma unroll
+    for (int nf = 0; nf < NFRAG; ++nf)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s1[nf][j] = 0.f; s2[nf][j] = 0.f; }
+
+    issue_next();
+    v4f acc[4][NFRAG];
+    int kc = 0, stage = 0;
+    const int nchunk = p.tpw * nkc;
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+        if (kc == 0) {
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+                for (int nf = 0; nf < NFRAG; ++nf) acc[mf][nf] = v4f{0.f, 0.f, 0.f, 0.f};
+        }
+        const char* wbuf = smW + kc * WBYTES;
+#pragma unroll
+        for (int c = 0; c < 4; ++c, ++stage) {
+            constexpr int dummy = 0; (void)dummy;
+            const int ry = c >> 1, rx = c & 1;
+            const int nrow = 4 + ry, ncol = 1 + rx;
+            const int poff = (stage & 1) * PBYTES;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            uint4 B[5][2];
+#pragma unroll
+            for (int r = 0; r < 5; ++r)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx)
+                    if (r < nrow && dx < ncol) B[r][dx] = *reinterpret_cast<const uint4*>(smem + poff + bx[dx] + r * PD * 64);
+            issue_next();
+#pragma unroll
+            for (int iy = 0; iy <= ry; ++iy)
+#pragma unroll
+                for (int ix = 0; ix <= rx; ++ix) {
+                    // ry = 0: ky = 1 at row offset 0; ry = 1: ky = 0 at offset 0, ky = 2 at offset 1 (x alike)
+                    const int ky = ry ? 2 * iy : 1, kx = rx ? 2 * ix : 1;
+                    const int t = ky * 3 + kx;
+                    uint4 afr[NFRAG];
+#pragma unroll
+                    for (int nf = 0; nf < NFRAG; ++nf) afr[nf] = *reinterpret_cast<const uint4*>(wbuf + (t * NT + nf * 16) * 64 + w_lane);
+#pragma unroll
+                    for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+                        for (int nf = 0; nf < NFRAG; ++nf) acc[mf][nf] = mma16v<TR>(afr[nf], B[mf + iy][ix], acc[mf][nf]);
+                }
+        }
+        if (++kc == nkc) {
+            kc = 0;
+            const int by0 = c_ty << 4, bx0 = c_tx << 4;
+            const int base_pix = (c_img * p.od[1] + by0) * p.od[2] + bx0;
+            if (++c_tx == ntx) { c_tx = 0; if (++c_ty == nty) { c_ty = 0; ++c_img; } }
+            tile_epilogue<TR, NFRAG>(p, acc, base_pix, rel0, rel_step, by0, bx0, wave, lr, g, n0, do_stats, s1, s2);
+        }
+    }
+    if (do_stats) flush_stats<NFRAG>(p, smem, s1, s2, wave, lr, g, n0, img_wg, slot);
+}
+
+template <class TR, int NFRAG>
+int launch_conv2d_s2_t(const IgemmParams& pin, hipStream_t st) {
+    IgemmParams p = pin;
+    if (!p.out1) p.out0_c = p.N;
+    constexpr int NT = NFRAG * 16;
+    const int nkc = p.K / (64 / TR::ESZ);
+    const size_t lds = (size_t)2 * 19 * 1024 + (size_t)nkc * 9 * NT * 64;
+    p.tpw = tiles_per_wg(p, NT);
+    auto kern = conv2d_s2_kernel<TR, NFRAG>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { mi_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return -2; }
+    }
+    dim3 grid(p.nb * p.ntile[1] * p.ntile[2] / p.tpw, p.N / NT, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { mi_set_error(std::string("conv2d s2 launch: ") + hipGetErrorString(e)); return -2; }
+    return 0;
 }
 
 template <class TR, int NFRAG, int KS, bool WRES>
@@ -401,23 +802,83 @@ int launch_conv2d_t(const IgemmParams& pin, hipStream_t st) {
 
 }  // namespace
 
-// Geometry this file serves: 2-D tensor, 16 x 16 tile, unit gather stride, one phase with 9 taps on an 18 x 18 patch
-// or one tap on a 16 x 16 patch, contraction channels in whole 64-byte chunks from either source.
-bool conv2d_dma_applicable(int dtype, const IgemmParams& p) {
+// Geometry this file serves: 2-D tensor, 16 x 16 base-pixel tile, unit gather stride, contraction channels in whole
+// 64-byte chunks from either source, and either
+//   1: one phase with 9 taps on an 18 x 18 patch or one tap on a 16 x 16 patch (output stride 1), or
+//   2: the four stride-2 scatter phases with 1 + 2 + 2 + 4 taps on a 17 x 17 patch (output stride 2), or
+//   3: gather stride 2 with 9 taps (four 17 x 17 polyphase patches), weights resident.
+// stride-2 gather: channel fragments per workgroup such that the weights of all chunks (9 taps) fit in 40 KiB
+static int s2_nfrag(int dtype, const IgemmParams& p) {
+    const int nkc = p.K / (64 / (dtype ? 2 : 4));
+    for (int nf = 4; nf >= 1; nf >>= 1)
+        if (p.N % (nf * 16) == 0 && (size_t)nkc * 9 * nf * 16 * 64 <= 40 * 1024) return nf;
+    return 0;
+}
+static int conv2d_dma_kind(int dtype, const IgemmParams& p) {
     const int kce = 64 / (dtype ? 2 : 4);
-    if (p.id[0] != 1 || p.tlog[0] != 0 || p.tlog[1] != 4 || p.tlog[2] != 4 || p.pd[0] != 1) return false;
-    if (p.sa != 1 || p.so != 1 || p.nphase != 1 || p.ksplit > 1) return false;
-    const int ntaps = p.phase_start[1];
-    const bool k3 = ntaps == 9 && p.pd[1] == 18 && p.pd[2] == 18, k1 = ntaps == 1 && p.pd[1] == 16 && p.pd[2] == 16;
-    if (!k3 && !k1) return false;
-    for (int t = 0; t < ntaps; ++t)
-        if (p.tap_off[t] != (k3 ? (t / 3) * 18 + t % 3 : 0)) return false;      // taps in patch order (igemm_geometry sorts them)
-    if (p.K % kce || (p.in0_c < p.K && p.in0_c % kce) || p.N % 16) return false;
-    if ((long long)p.id[1] >= 65536 || (long long)p.id[2] >= 65536) return false;
-    return true;
+    if (p.id[0] != 1 || p.tlog[0] != 0 || p.tlog[1] != 4 || p.tlog[2] != 4 || p.pd[0] != 1) return 0;
+    if (p.ksplit > 1) return 0;
+    if (p.K % kce || (p.in0_c < p.K && p.in0_c % kce) || p.N % 16) return 0;
+    if ((long long)p.id[1] >= 32768 || (long long)p.id[2] >= 32768) return 0;
+    if (p.sa == 2) {
+        // stride-2 gather: 9 taps in kernel order on a 33 x 33 patch starting at offset -1; weights of all chunks resident
+        if (p.so != 1 || p.nphase != 1 || p.phase_start[1] != 9 || p.pd[1] != 33 || p.pd[2] != 33) return 0;
+        if (p.omin[1] != -1 || p.omin[2] != -1) return 0;
+        for (int t = 0; t < 9; ++t)
+            if (p.tap_off[t] != (t / 3) * 33 + t % 3) return 0;
+        if (s2_nfrag(dtype, p) == 0) return 0;
+        return 3;
+    }
+    if (p.sa != 1) return 0;
+    if (p.so == 1 && p.nphase == 1) {
+        const int ntaps = p.phase_start[1];
+        const bool k3 = ntaps == 9 && p.pd[1] == 18 && p.pd[2] == 18, k1 = ntaps == 1 && p.pd[1] == 16 && p.pd[2] == 16;
+        if (!k3 && !k1) return 0;
+        for (int t = 0; t < ntaps; ++t)
+            if (p.tap_off[t] != (k3 ? (t / 3) * 18 + t % 3 : 0)) return 0;      // taps in patch order (igemm_geometry sorts them)
+        return 1;
+    }
+    if (p.so == 2 && p.nphase == 4 && p.pd[1] == 17 && p.pd[2] == 17 && p.phase_start[4] == 9) {
+        if (p.omin[1] != 0 || p.omin[2] != 0) return 0;
+        for (int ph = 0; ph < 4; ++ph)
+            if (p.phase_off[ph][1] != (ph >> 1) || p.phase_off[ph][2] != (ph & 1)) return 0;
+        for (int t = 0; t < 9; ++t) {
+            if (t < p.phase_start[ph_of_tap(t)] || t >= p.phase_start[ph_of_tap(t) + 1]) return 0;
+            if (p.tap_off[t] != ph_dy(t) * 17 + ph_dx(t)) return 0;
+        }
+        if (p.id[1] * 2 != p.od[1] || p.id[2] * 2 != p.od[2]) return 0;
+        return 2;
+    }
+    return 0;
+}
+bool conv2d_dma_applicable(int dtype, const IgemmParams& p) {
+    static const bool no_phase = getenv("MI_NO_CONV_PHASE") != nullptr;
+    const int k = conv2d_dma_kind(dtype, p);
+    static const bool no_s2 = getenv("MI_NO_CONV_S2") != nullptr;
+    return k == 1 || (k == 2 && !no_phase) || (k == 3 && !no_s2);
+}
+
+// name of the kernel launch_conv2d_dma picks, as the step tables print it
+void conv2d_dma_label(int dtype, const IgemmParams& p, char* buf, size_t n) {
+    const char* tr = dtype ? "BF16" : "F32";
+    const int kind = conv2d_dma_kind(dtype, p);
+    if (kind == 3) snprintf(buf, n, "conv2d_s2_kernel<%s,%d>", tr, s2_nfrag(dtype, p));
+    else if (kind == 2) snprintf(buf, n, "conv2d_phase_kernel<%s,%d>", tr, (p.N % 32 == 0) ? 2 : 1);
+    else snprintf(buf, n, "conv2d_dma_kernel<%s,%d>", tr, (p.N % 64 == 0) ? 4 : (p.N % 32 == 0) ? 2 : 1);
 }
 
 int launch_conv2d_dma(int dtype, const IgemmParams& p, hipStream_t st) {
+    if (conv2d_dma_kind(dtype, p) == 3) {
+        const int nfs = s2_nfrag(dtype, p);
+#define S2_CASE(TRT) do { if (nfs == 4) return launch_conv2d_s2_t<TRT, 4>(p, st); if (nfs == 2) return launch_conv2d_s2_t<TRT, 2>(p, st); return launch_conv2d_s2_t<TRT, 1>(p, st); } while (0)
+        if (dtype) S2_CASE(BF16); else S2_CASE(F32);
+#undef S2_CASE
+    }
+    if (conv2d_dma_kind(dtype, p) == 2) {
+        const int nfp = (p.N % 32 == 0) ? 2 : 1;
+        if (dtype) return nfp == 2 ? launch_conv2d_phase_t<BF16, 2>(p, st) : launch_conv2d_phase_t<BF16, 1>(p, st);
+        return nfp == 2 ? launch_conv2d_phase_t<F32, 2>(p, st) : launch_conv2d_phase_t<F32, 1>(p, st);
+    }
     const int ntaps = p.phase_start[1];
     const int nkc = p.K / (64 / (dtype ? 2 : 4));
     const int nf = (p.N % 64 == 0) ? 4 : (p.N % 32 == 0) ? 2 : 1;

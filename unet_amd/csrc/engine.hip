@@ -227,7 +227,7 @@ struct Builder {
         char kb[96];
         snprintf(kb, sizeof(kb), "igemm_kernel<%s,%d,%d>", u.dt ? "BF16" : "F32", cps, nfrag);
         if (conv2d_dma_enabled() && conv2d_dma_applicable(u.dt, p))
-            snprintf(kb, sizeof(kb), "conv2d_dma_kernel<%s,%d>", u.dt ? "BF16" : "F32", (N % 64 == 0) ? 4 : (N % 32 == 0) ? 2 : 1);
+            conv2d_dma_label(u.dt, p, kb, sizeof(kb));
         s.kernel = kb;
         double bpix = (double)p.bd[0] * p.bd[1] * p.bd[2] * u.nb;
         s.work = 2.0 * bpix * (double)(*ntaps_out) * K * N; s.work_is_flops = 1;
