@@ -35,6 +35,10 @@ CASES = [
     (2, (8, 8), 384, 64, 3, 2, True),
     (2, (16, 16), 64, 16, 3, 2, True),
     (2, (12, 20), 128, 32, 3, 2, True),
+    (2, (18, 30), 32, 64, 3, 2, False),      # odd output extents: ragged tiles of the stride-2 gather / scatter kernels
+    (2, (36, 20), 64, 128, 3, 2, False),     # two contraction chunks with resident weights
+    (2, (10, 14), 64, 32, 3, 2, True),
+    (2, (40, 24), 64, 64, 3, 1, False),      # several tiles per workgroup, last tile row ragged
     (3, (8, 8, 8), 16, 16, 3, 1, False),
     (3, (4, 8, 12), 32, 64, 3, 1, False),
     (3, (8, 8, 8), 16, 64, 3, 2, False),
