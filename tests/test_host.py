@@ -222,3 +222,23 @@ def test_conv2d_dma_fill_is_the_inverse_of_the_fragment_permutation():
             src_chunk = slot ^ _swz(x)
             assert (src_chunk ^ _swz(x)) == slot
             assert 0 <= src_chunk < 4
+
+
+def test_conv2d_k16_fragment_reads_are_bank_conflict_free():
+    # 32-byte pixel rows, unpermuted; lanes 0..31 read tap A's pixel, lanes 32..63 tap B's (or a zero weight row)
+    pd = 18
+    for step in range(5):
+        for wrow in range(0, 16, 4):
+            for mf in range(4):
+                def addr(lane, step=step, wrow=wrow, mf=mf):
+                    lr, g = lane & 15, lane >> 4
+                    t = 2 * step + (g >> 1)
+                    if t >= 9:
+                        return 22 * 1024 + (9 * 16 + lr) * 32 + (g & 1) * 16
+                    return ((wrow + mf + t // 3) * pd + lr + t % 3) * 32 + (g & 1) * 16
+                assert _max_ways(addr) == 1, (step, wrow, mf)
+    for t in range(10):
+        def waddr(lane, t=t):
+            lr, g = lane & 15, lane >> 4
+            return (t * 16 + lr) * 32 + (g & 1) * 16
+        assert _max_ways(waddr) == 1

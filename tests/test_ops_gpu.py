@@ -39,6 +39,10 @@ CASES = [
     (2, (36, 20), 64, 128, 3, 2, False),     # two contraction chunks with resident weights
     (2, (10, 14), 64, 32, 3, 2, True),
     (2, (40, 24), 64, 64, 3, 1, False),      # several tiles per workgroup, last tile row ragged
+    (2, (24, 40), 16, 32, 3, 1, False),      # 16 contraction channels: two taps per MFMA step (bf16)
+    (2, (20, 20), 16, 64, 3, 1, False),
+    (2, (36, 28), 16, 32, 3, 2, False),      # the same with stride 2
+    (2, (14, 10), 64, 16, 3, 2, True),       # its data gradient gathers 16 channels with stride 2
     (3, (8, 8, 8), 16, 16, 3, 1, False),
     (3, (4, 8, 12), 32, 64, 3, 1, False),
     (3, (8, 8, 8), 16, 64, 3, 2, False),

@@ -770,6 +770,323 @@ int launch_conv2d_s2_t(const IgemmParams& pin, hipStream_t st) {
     return 0;
 }
 
+// ---- 16 contraction channels (bf16): 32-byte pixel rows, two taps per MFMA contraction step ---------------------------
+// With K = 16 a 16x16x32 MFMA would run half empty.  Here contraction slots 0..15 carry one tap and 16..31 the next:
+// lanes 0..31 (g = 0, 1) read tap A's pixel and weight row, lanes 32..63 tap B's, so the nine taps take five steps
+// (the ninth pairs with an all-zero weight block, and its partner lanes read that zero block as their "pixels").
+// Rows are unpadded and unpermuted: 32-byte rows are conflict-free for these reads as they are.  One stage = one tile
+// (the whole contraction fits one step set); patches double-buffered, the weight image (10 tap blocks) resident.
+__host__ __device__ constexpr int k16_tap(int step, int hi) { return 2 * step + hi; }          // 9 = the zero block
+
+template <int NFRAG>
+__global__ __launch_bounds__(256, 2) void conv2d_k16_kernel(const IgemmParams p) {
+    using TR = BF16;
+    constexpr int ESZ = 2;
+    constexpr int NT = NFRAG * 16;
+    constexpr int PD = 18, PP = PD * PD;
+    constexpr int NIP = (PP + 31) / 32;            // 11 DMA wave-instructions per patch (32 pixels each)
+    constexpr int PBYTES = NIP * 1024;
+    constexpr int NUP = (NIP + 3) / 4;
+    constexpr int WROWS = 10 * NT;
+    constexpr int NIW = WROWS / 32;
+    constexpr int NUW = (NIW + 3) / 4;
+    constexpr int NSTEP = 5;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    char* const smP = smem;
+    char* const smW = smem + 2 * PBYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, g = lane >> 4;
+    const int H = p.id[1], W = p.id[2];
+    const int ntx = p.ntile[2], nty = p.ntile[1];
+    const int tile0 = blockIdx.x * p.tpw;
+    const int n0 = blockIdx.y * NT;
+    const int slot = blockIdx.x % MI_NSLOT;
+    const int spb = p.in0_pitch * ESZ;
+
+    int d_off[NUP], d_yx[NUP];
+#pragma unroll
+    for (int u = 0; u < NUP; ++u) {
+        const int pix = ((wave + 4 * u) % NIP) * 32 + (lane >> 1);
+        const int py = pix / PD, px = pix - py * PD;
+        d_off[u] = (py * W + px) * spb + (lane & 1) * 16;
+        d_yx[u] = pix < PP ? ((py << 16) | px) : -1;
+    }
+    const char* const zero = reinterpret_cast<const char*>(g_zero_page) + (lane & 1) * 16;
+
+    int q_img, q_ty, q_tx, q_tile = 0;
+    {
+        const int tiles_img = ntx * nty;
+        q_img = tile0 / tiles_img;
+        const int r = tile0 - q_img * tiles_img;
+        q_ty = r / ntx; q_tx = r - q_ty * ntx;
+    }
+    int c_img = q_img, c_ty = q_ty, c_tx = q_tx;
+    const int img_wg = q_img;
+
+    auto issue_next = [&]() {
+        if (q_tile < p.tpw) {
+            const int iy0 = (q_ty << 4) + p.omin[1], ix0 = (q_tx << 4) + p.omin[2];
+            const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + PD <= H && ix0 + PD <= W;
+            const char* pb = p.in0 + (((long long)q_img * H + iy0) * W + ix0) * spb + p.in0_coff * ESZ;
+            char* dst = smP + (q_tile & 1) * PBYTES;
+#pragma unroll
+            for (int u = 0; u < NUP; ++u) {
+                const int i = (wave + 4 * u) % NIP;
+                bool ok = d_yx[u] >= 0;
+                if (!interior) ok = ok && (unsigned)(iy0 + (d_yx[u] >> 16)) < (unsigned)H && (unsigned)(ix0 + (d_yx[u] & 0xffff)) < (unsigned)W;
+                dma16(ok ? pb + d_off[u] : zero, dst + i * 1024);
+            }
+        }
+        ++q_tile;
+        if (++q_tx == ntx) { q_tx = 0; if (++q_ty == nty) { q_ty = 0; ++q_img; } }
+    };
+
+    // resident weights: rows (tap, n) of 32 bytes, tap 9 all zero
+#pragma unroll
+    for (int u = 0; u < NUW; ++u) {
+        const int i = (wave + 4 * u) % NIW;
+        const int row = i * 32 + (lane >> 1);
+        const int tl = row / NT, r = row - tl * NT;
+        const int n = n0 + chan_of_row_v<NFRAG>(r >> 4, r & 15);
+        dma16(tl < 9 ? p.w + ((size_t)(tl * p.N + n) * 16) * ESZ + (lane & 1) * 16 : zero, smW + i * 1024);
+    }
+
+    // per-lane fragment offsets of the five steps: the lane's tap is 2 * step + (g >> 1)
+    int bq[NSTEP], aw[NSTEP];
+#pragma unroll
+    for (int st = 0; st < NSTEP; ++st) {
+        const int t = k16_tap(st, g >> 1);
+        aw[st] = (t * NT + lr) * 32 + (g & 1) * 16;
+        if (t < 9) bq[st] = ((wave * 4 + t / 3) * PD + lr + t % 3) * 32 + (g & 1) * 16;
+        else bq[st] = -1;                          // reads the zero weight block instead of a patch
+    }
+    const int zrow = 2 * PBYTES + (9 * NT + lr) * 32 + (g & 1) * 16;   // smem offset of a zero row
+    const int rel0 = (wave * 4) * p.od[2] + lr;
+    const int rel_step = p.od[2];
+
+    const bool do_stats = p.stats != nullptr;
+    float s1[NFRAG][4], s2[NFRAG][4];
+#pragma unroll
+    for (int nf = 0; nf < NFRAG; ++nf)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s1[nf][j] = 0.f; s2[nf][j] = 0.f; }
+
+    issue_next();
+    for (int tile = 0; tile < p.tpw; ++tile) {
+        const int poff = (tile & 1) * PBYTES;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        uint4 B[NSTEP][4];
+#pragma unroll
+        for (int st = 0; st < NSTEP; ++st)
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf)
+                B[st][mf] = *reinterpret_cast<const uint4*>(smem + (bq[st] >= 0 ? poff + bq[st] + mf * PD * 32 : zrow));
+        issue_next();
+        v4f acc[4][NFRAG];
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < NFRAG; ++nf) acc[mf][nf] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < NSTEP; ++st) {
+            uint4 afr[NFRAG];
+#pragma unroll
+            for (int nf = 0; nf < NFRAG; ++nf) afr[nf] = *reinterpret_cast<const uint4*>(smW + aw[st] + nf * 16 * 32);
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+                for (int nf = 0; nf < NFRAG; ++nf) acc[mf][nf] = mma16v<TR>(afr[nf], B[st][mf], acc[mf][nf]);
+        }
+        const int by0 = c_ty << 4, bx0 = c_tx << 4;
+        const int base_pix = (c_img * p.od[1] + by0) * p.od[2] + bx0;
+        if (++c_tx == ntx) { c_tx = 0; if (++c_ty == nty) { c_ty = 0; ++c_img; } }
+        tile_epilogue<TR, NFRAG>(p, acc, base_pix, rel0, rel_step, by0, bx0, wave, lr, g, n0, do_stats, s1, s2);
+    }
+    if (do_stats) flush_stats<NFRAG>(p, smem, s1, s2, wave, lr, g, n0, img_wg, slot);
+}
+
+template <int NFRAG>
+int launch_conv2d_k16_t(const IgemmParams& pin, hipStream_t st) {
+    IgemmParams p = pin;
+    if (!p.out1) p.out0_c = p.N;
+    constexpr int NT = NFRAG * 16;
+    const size_t lds = (size_t)2 * 11 * 1024 + (size_t)10 * NT * 32;
+    p.tpw = tiles_per_wg(p, NT);
+    auto kern = conv2d_k16_kernel<NFRAG>;
+    dim3 grid(p.nb * p.ntile[1] * p.ntile[2] / p.tpw, p.N / NT, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { mi_set_error(std::string("conv2d k16 launch: ") + hipGetErrorString(e)); return -2; }
+    return 0;
+}
+
+// ---- stride-2 gather with 16 contraction channels (bf16): the component stages of conv2d_s2_kernel on 32-byte rows,
+// two taps per MFMA step as in conv2d_k16_kernel.  Steps: component (0,0): tap (1,1) with the zero block; (0,1): taps
+// (1,0) (1,2); (1,0): taps (0,1) (2,1); (1,1): taps (0,0) (0,2), then (2,0) (2,2).
+__host__ __device__ constexpr int s2k16_comp(int step) { return step < 3 ? step : 3; }
+__host__ __device__ constexpr int s2k16_tap(int step, int hi) {           // weight slot (ky * 3 + kx), 9 = zero block
+    return step == 0 ? (hi ? 9 : 4) : step == 1 ? (hi ? 5 : 3) : step == 2 ? (hi ? 7 : 1) : step == 3 ? (hi ? 2 : 0) : (hi ? 8 : 6);
+}
+__host__ __device__ constexpr int s2k16_iy(int step, int hi) { return step == 2 ? hi : step == 4 ? 1 : 0; }   // row offset in the component patch
+__host__ __device__ constexpr int s2k16_ix(int step, int hi) { return (step == 1 || step >= 3) ? hi : 0; }
+
+template <int NFRAG>
+__global__ __launch_bounds__(256, 2) void conv2d_s2k16_kernel(const IgemmParams p) {
+    using TR = BF16;
+    constexpr int ESZ = 2;
+    constexpr int NT = NFRAG * 16;
+    constexpr int PD = 17, PP = PD * PD;
+    constexpr int NIP = (PP + 31) / 32;            // 10
+    constexpr int PBYTES = NIP * 1024;
+    constexpr int NUP = (NIP + 3) / 4;
+    constexpr int WROWS = 10 * NT;
+    constexpr int NIW = WROWS / 32;
+    constexpr int NUW = (NIW + 3) / 4;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    char* const smP = smem;
+    char* const smW = smem + 2 * PBYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, g = lane >> 4;
+    const int H = p.id[1], W = p.id[2];
+    const int ntx = p.ntile[2], nty = p.ntile[1];
+    const int tile0 = blockIdx.x * p.tpw;
+    const int n0 = blockIdx.y * NT;
+    const int slot = blockIdx.x % MI_NSLOT;
+    const int nstage = p.tpw * 4;
+    const int spb = p.in0_pitch * ESZ;
+
+    int d_off[NUP], d_yx[NUP];
+#pragma unroll
+    for (int u = 0; u < NUP; ++u) {
+        const int pix = ((wave + 4 * u) % NIP) * 32 + (lane >> 1);
+        const int py = pix / PD, px = pix - py * PD;
+        d_off[u] = (2 * py * W + 2 * px) * spb + (lane & 1) * 16;
+        d_yx[u] = pix < PP ? ((py << 16) | px) : -1;
+    }
+    const char* const zero = reinterpret_cast<const char*>(g_zero_page) + (lane & 1) * 16;
+
+    int q_img, q_ty, q_tx, q_c = 0, q_stage = 0;
+    {
+        const int tiles_img = ntx * nty;
+        q_img = tile0 / tiles_img;
+        const int r = tile0 - q_img * tiles_img;
+        q_ty = r / ntx; q_tx = r - q_ty * ntx;
+    }
+    int c_img = q_img, c_ty = q_ty, c_tx = q_tx;
+    const int img_wg = q_img;
+
+    auto issue_next = [&]() {
+        if (q_stage < nstage) {
+            const int ry = q_c >> 1, rx = q_c & 1;
+            const int iy0 = (q_ty << 5) - ry, ix0 = (q_tx << 5) - rx;
+            const char* pb = p.in0 + (((long long)q_img * H + iy0) * W + ix0) * spb + p.in0_coff * ESZ;
+            char* dst = smP + (q_stage & 1) * PBYTES;
+#pragma unroll
+            for (int u = 0; u < NUP; ++u) {
+                const int i = (wave + 4 * u) % NIP;
+                const int iy = iy0 + 2 * (d_yx[u] >> 16), ix = ix0 + 2 * (d_yx[u] & 0xffff);
+                const bool ok = d_yx[u] >= 0 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                dma16(ok ? pb + d_off[u] : zero, dst + i * 1024);
+            }
+        }
+        ++q_stage;
+        if (++q_c == 4) { q_c = 0; if (++q_tx == ntx) { q_tx = 0; if (++q_ty == nty) { q_ty = 0; ++q_img; } } }
+    };
+
+#pragma unroll
+    for (int u = 0; u < NUW; ++u) {
+        const int i = (wave + 4 * u) % NIW;
+        const int row = i * 32 + (lane >> 1);
+        const int tl = row / NT, r = row - tl * NT;
+        const int n = n0 + chan_of_row_v<NFRAG>(r >> 4, r & 15);
+        dma16(tl < 9 ? p.w + ((size_t)(tl * p.N + n) * 16) * ESZ + (lane & 1) * 16 : zero, smW + i * 1024);
+    }
+
+    int bq[5], aw[5];
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+        const int hi = g >> 1;
+        const int t = hi ? s2k16_tap(st, 1) : s2k16_tap(st, 0);
+        const int iy = hi ? s2k16_iy(st, 1) : s2k16_iy(st, 0), ix = hi ? s2k16_ix(st, 1) : s2k16_ix(st, 0);
+        aw[st] = (t * NT + lr) * 32 + (g & 1) * 16;
+        bq[st] = t < 9 ? ((wave * 4 + iy) * PD + lr + ix) * 32 + (g & 1) * 16 : -1;
+    }
+    const int zrow = 2 * PBYTES + (9 * NT + lr) * 32 + (g & 1) * 16;
+    const int rel0 = (wave * 4) * p.od[2] + lr;
+    const int rel_step = p.od[2];
+
+    const bool do_stats = p.stats != nullptr;
+    float s1[NFRAG][4], s2[NFRAG][4];
+#pragma unroll
+    for (int nf = 0; nf < NFRAG; ++nf)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s1[nf][j] = 0.f; s2[nf][j] = 0.f; }
+
+    issue_next();
+    int stage = 0;
+    for (int tile = 0; tile < p.tpw; ++tile) {
+        v4f acc[4][NFRAG];
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < NFRAG; ++nf) acc[mf][nf] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c, ++stage) {
+            const int poff = (stage & 1) * PBYTES;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            constexpr int dummy = 0; (void)dummy;
+            const int st0 = c, nst = c == 3 ? 2 : 1;     // steps of this component: c, and 4 after 3
+            uint4 B[2][4];
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int mf = 0; mf < 4; ++mf)
+                    if (k < nst) B[k][mf] = *reinterpret_cast<const uint4*>(smem + (bq[st0 + k] >= 0 ? poff + bq[st0 + k] + mf * PD * 32 : zrow));
+            issue_next();
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (k < nst) {
+                    uint4 afr[NFRAG];
+#pragma unroll
+                    for (int nf = 0; nf < NFRAG; ++nf) afr[nf] = *reinterpret_cast<const uint4*>(smW + aw[st0 + k] + nf * 16 * 32);
+#pragma unroll
+                    for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+                        for (int nf = 0; nf < NFRAG; ++nf) acc[mf][nf] = mma16v<TR>(afr[nf], B[k][mf], acc[mf][nf]);
+                }
+            }
+        }
+        const int by0 = c_ty << 4, bx0 = c_tx << 4;
+        const int base_pix = (c_img * p.od[1] + by0) * p.od[2] + bx0;
+        if (++c_tx == ntx) { c_tx = 0; if (++c_ty == nty) { c_ty = 0; ++c_img; } }
+        tile_epilogue<TR, NFRAG>(p, acc, base_pix, rel0, rel_step, by0, bx0, wave, lr, g, n0, do_stats, s1, s2);
+    }
+    if (do_stats) flush_stats<NFRAG>(p, smem, s1, s2, wave, lr, g, n0, img_wg, slot);
+}
+
+template <int NFRAG>
+int launch_conv2d_s2k16_t(const IgemmParams& pin, hipStream_t st) {
+    IgemmParams p = pin;
+    if (!p.out1) p.out0_c = p.N;
+    constexpr int NT = NFRAG * 16;
+    const size_t lds = (size_t)2 * 10 * 1024 + (size_t)10 * NT * 32;
+    p.tpw = tiles_per_wg(p, NT);
+    auto kern = conv2d_s2k16_kernel<NFRAG>;
+    dim3 grid(p.nb * p.ntile[1] * p.ntile[2] / p.tpw, p.N / NT, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { mi_set_error(std::string("conv2d s2k16 launch: ") + hipGetErrorString(e)); return -2; }
+    return 0;
+}
+
 template <class TR, int NFRAG, int KS, bool WRES>
 int launch_conv2d_t(const IgemmParams& pin, hipStream_t st) {
     IgemmParams p = pin;
@@ -806,7 +1123,9 @@ int launch_conv2d_t(const IgemmParams& pin, hipStream_t st) {
 // 64-byte chunks from either source, and either
 //   1: one phase with 9 taps on an 18 x 18 patch or one tap on a 16 x 16 patch (output stride 1), or
 //   2: the four stride-2 scatter phases with 1 + 2 + 2 + 4 taps on a 17 x 17 patch (output stride 2), or
-//   3: gather stride 2 with 9 taps (four 17 x 17 polyphase patches), weights resident.
+//   3: gather stride 2 with 9 taps (four 17 x 17 polyphase patches), weights resident, or
+//   4: bf16 with 16 contraction channels, 3 x 3, unit stride (two taps per MFMA step), or
+//   5: the same with gather stride 2 (component stages).
 // stride-2 gather: channel fragments per workgroup such that the weights of all chunks (9 taps) fit in 40 KiB
 static int s2_nfrag(int dtype, const IgemmParams& p) {
     const int nkc = p.K / (64 / (dtype ? 2 : 4));
@@ -818,6 +1137,19 @@ static int conv2d_dma_kind(int dtype, const IgemmParams& p) {
     const int kce = 64 / (dtype ? 2 : 4);
     if (p.id[0] != 1 || p.tlog[0] != 0 || p.tlog[1] != 4 || p.tlog[2] != 4 || p.pd[0] != 1) return 0;
     if (p.ksplit > 1) return 0;
+    if (dtype && p.K == 16 && p.in0_c >= 16 && p.N % 16 == 0 && p.sa == 1 && p.so == 1 && p.nphase == 1 && p.phase_start[1] == 9 &&
+        p.pd[1] == 18 && p.pd[2] == 18 && p.id[1] < 32768 && p.id[2] < 32768) {
+        // 16 bf16 contraction channels from one source, 3 x 3 taps in patch order
+        for (int t = 0; t < 9; ++t)
+            if (p.tap_off[t] != (t / 3) * 18 + t % 3) return 0;
+        return 4;
+    }
+    if (dtype && p.K == 16 && p.in0_c >= 16 && p.N % 16 == 0 && p.sa == 2 && p.so == 1 && p.nphase == 1 && p.phase_start[1] == 9 &&
+        p.pd[1] == 33 && p.pd[2] == 33 && p.omin[1] == -1 && p.omin[2] == -1 && p.id[1] < 32768 && p.id[2] < 32768) {
+        for (int t = 0; t < 9; ++t)
+            if (p.tap_off[t] != (t / 3) * 33 + t % 3) return 0;
+        return 5;
+    }
     if (p.K % kce || (p.in0_c < p.K && p.in0_c % kce) || p.N % 16) return 0;
     if ((long long)p.id[1] >= 32768 || (long long)p.id[2] >= 32768) return 0;
     if (p.sa == 2) {
@@ -855,19 +1187,32 @@ bool conv2d_dma_applicable(int dtype, const IgemmParams& p) {
     static const bool no_phase = getenv("MI_NO_CONV_PHASE") != nullptr;
     const int k = conv2d_dma_kind(dtype, p);
     static const bool no_s2 = getenv("MI_NO_CONV_S2") != nullptr;
-    return k == 1 || (k == 2 && !no_phase) || (k == 3 && !no_s2);
+    static const bool no_k16 = getenv("MI_NO_CONV_K16") != nullptr;
+    return k == 1 || (k == 2 && !no_phase) || (k == 3 && !no_s2) || ((k == 4 || k == 5) && !no_k16);
 }
 
 // name of the kernel launch_conv2d_dma picks, as the step tables print it
 void conv2d_dma_label(int dtype, const IgemmParams& p, char* buf, size_t n) {
     const char* tr = dtype ? "BF16" : "F32";
     const int kind = conv2d_dma_kind(dtype, p);
-    if (kind == 3) snprintf(buf, n, "conv2d_s2_kernel<%s,%d>", tr, s2_nfrag(dtype, p));
+    if (kind == 5) snprintf(buf, n, "conv2d_s2k16_kernel<%d>", (p.N % 64 == 0) ? 4 : (p.N % 32 == 0) ? 2 : 1);
+    else if (kind == 4) snprintf(buf, n, "conv2d_k16_kernel<%d>", (p.N % 64 == 0) ? 4 : (p.N % 32 == 0) ? 2 : 1);
+    else if (kind == 3) snprintf(buf, n, "conv2d_s2_kernel<%s,%d>", tr, s2_nfrag(dtype, p));
     else if (kind == 2) snprintf(buf, n, "conv2d_phase_kernel<%s,%d>", tr, (p.N % 32 == 0) ? 2 : 1);
     else snprintf(buf, n, "conv2d_dma_kernel<%s,%d>", tr, (p.N % 64 == 0) ? 4 : (p.N % 32 == 0) ? 2 : 1);
 }
 
 int launch_conv2d_dma(int dtype, const IgemmParams& p, hipStream_t st) {
+    if (conv2d_dma_kind(dtype, p) == 5) {
+        if (p.N % 64 == 0) return launch_conv2d_s2k16_t<4>(p, st);
+        if (p.N % 32 == 0) return launch_conv2d_s2k16_t<2>(p, st);
+        return launch_conv2d_s2k16_t<1>(p, st);
+    }
+    if (conv2d_dma_kind(dtype, p) == 4) {
+        if (p.N % 64 == 0) return launch_conv2d_k16_t<4>(p, st);
+        if (p.N % 32 == 0) return launch_conv2d_k16_t<2>(p, st);
+        return launch_conv2d_k16_t<1>(p, st);
+    }
     if (conv2d_dma_kind(dtype, p) == 3) {
         const int nfs = s2_nfrag(dtype, p);
 #define S2_CASE(TRT) do { if (nfs == 4) return launch_conv2d_s2_t<TRT, 4>(p, st); if (nfs == 2) return launch_conv2d_s2_t<TRT, 2>(p, st); return launch_conv2d_s2_t<TRT, 1>(p, st); } while (0)
