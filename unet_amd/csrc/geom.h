@@ -157,6 +157,9 @@ inline bool igemm_geometry(const ConvShape& s, int dir, IgemmParams& p, int kidx
         }
     for (int d = 0; d < 3; ++d) halo[d] = omax[d] - p.omin[d];
     choose_tile(s.ndim, p.bd, p.sa, halo, 2900, p.tlog);
+    // 2-D one-tap layers: every tile shape stages the same pixels; the square tile is the one the asynchronously
+    // staged kernels serve
+    if (s.ndim == 2 && t.n == 1 && p.bd[1] >= 16 && p.bd[2] >= 16) { p.tlog[0] = 0; p.tlog[1] = 4; p.tlog[2] = 4; }
     for (int d = 0; d < 3; ++d) {
         const int T = 1 << p.tlog[d];
         p.ntile[d] = (p.bd[d] + T - 1) / T;
