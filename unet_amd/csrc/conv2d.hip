@@ -1,21 +1,29 @@
-// Two-dimensional gather-GEMM convolution with asynchronous staging (gfx950).
+// Two-dimensional gather-GEMM convolutions with asynchronous staging (gfx950).
 //
-// Same contract as igemm_kernel (kparams.h, IgemmParams) for 2-D tensors gathered with unit stride and a 16 x 16
-// pixel tile: 3 x 3 taps (18 x 18 patch) or one tap.  What differs from the register-staged kernels of igemm.hip:
+// Same contract as igemm_kernel (kparams.h, IgemmParams) for 2-D tensors and a 16 x 16 base-pixel tile.  Five kernels:
+//   conv2d_dma_kernel     unit stride, 3 x 3 taps (18 x 18 patch) or one tap (16 x 16)
+//   conv2d_phase_kernel   the four stride-2 scatter phases (transposed convolution, data gradient of a stride-2
+//                         convolution) from one 17 x 17 patch
+//   conv2d_s2_kernel      stride-2 gather (stride-2 convolution, data gradient of the transposed convolution) as four
+//                         polyphase component stages
+//   conv2d_k16_kernel, conv2d_s2k16_kernel   the unit-stride and stride-2 gather forms for 16 bf16 contraction
+//                         channels: 32-byte pixel rows, two taps per MFMA contraction step
+// What they share, and what differs from the register-staged kernels of igemm.hip:
 //
 //  * the input patch and the weight tile of a stage go from global memory straight into LDS (global_load ... lds,
 //    16 bytes per lane, no registers in between), the loads of stage s + 1 are issued before the MFMA loop of
 //    stage s and land while it runs: one barrier per stage, and a workgroup that walks several tiles has the next
 //    tile's patch in flight during the current tile's arithmetic and epilogue;
 //  * LDS rows are unpadded 64-byte pixel (or weight) rows; the 16-byte chunk c of row r sits in slot
-//    c ^ (((x >> 2) & 1) << 1), x = the pixel's column in the patch (the row number for weights).  The DMA writes LDS lane-linearly, so the permutation is applied to the per-lane
-//    SOURCE address, and again on the fragment reads; with it the 16 lanes of every ds_read_b128 service group hit
-//    16 different 16-byte slots for any tap offset (checked exhaustively on the host, tests/test_host.py);
+//    c ^ (((x >> 2) & 1) << 1), x = the pixel's column in the patch (the row number for weights).  The DMA writes LDS
+//    lane-linearly, so the permutation is applied to the per-lane SOURCE address, and again on the fragment reads;
+//    with it the 16 lanes of every ds_read_b128 service group hit 16 different 16-byte slots for any tap offset
+//    (checked exhaustively on the host, tests/test_host.py); 32-byte rows need no permutation;
 //  * pixels outside the tensor are read from a zero page, so the staged image needs no separate clearing pass.
 //
-// Stages: with resident weights (all contraction chunks of all taps fit next to two patch buffers) a stage is one
-// (tile, chunk) and multiplies all taps; otherwise a stage is one (tile, chunk, tap group) whose weights are
-// double-buffered like the patches.
+// Stages of conv2d_dma_kernel: with resident weights (all contraction chunks of all taps fit next to two patch
+// buffers) a stage is one (tile, chunk) and multiplies all taps; otherwise a stage is one kernel row of a
+// (tile, chunk) whose weights go through a ring of three buffers.
 #include "common.h"
 #include "kparams.h"
 
@@ -534,7 +542,6 @@ __global__ __launch_bounds__(256, 2) void conv2d_phase_kernel(const IgemmParams 
                 for (int nf = 0; nf < NFRAG; ++nf)
                     afr[(t + 1) & 1][nf] = *reinterpret_cast<const uint4*>(wbuf + ((t + 1) * NT + nf * 16) * 64 + w_lane);
             }
-            constexpr int dummy = 0; (void)dummy;
             const int ph = ph_of_tap(t), dy = ph_dy(t), dx = ph_dx(t);
 #pragma unroll
             for (int mf = 0; mf < 4; ++mf)
@@ -709,7 +716,6 @@ __global__ __launch_bounds__(256, 2) void conv2d_s2_kernel(const IgemmParams p) 
         const char* wbuf = smW + kc * WBYTES;
 #pragma unroll
         for (int c = 0; c < 4; ++c, ++stage) {
-            constexpr int dummy = 0; (void)dummy;
             const int ry = c >> 1, rx = c & 1;
             const int nrow = 4 + ry, ncol = 1 + rx;
             const int poff = (stage & 1) * PBYTES;
@@ -1042,7 +1048,6 @@ __global__ __launch_bounds__(256, 2) void conv2d_s2k16_kernel(const IgemmParams 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            constexpr int dummy = 0; (void)dummy;
             const int st0 = c, nst = c == 3 ? 2 : 1;     // steps of this component: c, and 4 after 3
             uint4 B[2][4];
 #pragma unroll
