@@ -84,7 +84,7 @@ def test_flop_accounting_matches_survey_figures():
     assert abs(p3.flops(False) / 4 / 1e9 - 9.904) < 0.002
     # one launch per layer op; every conv of the network appears once in the forward list
     kernels = [s["kernel"] for s in p.steps(False)]
-    nconv = sum(k.startswith(("igemm_kernel", "c1_s2", "stencil")) for k in kernels)
+    nconv = sum(k.startswith(("igemm_kernel", "conv2d_", "c1_s2", "stencil")) for k in kernels)
     assert nconv == 23 - 4  # the 4 stride-2 residual convs share their unit0 launch
     assert p.workspace_bytes < 8 << 30
 
