@@ -881,6 +881,9 @@ bool build(mi_unet& u) {
                     B.add_reduce(po, pb, p.nsplit, KK, 2 * cout, 1, cout, cout, KK, nat, P + ".residual.weight", P + ".residual.bias");
                 }
             }
+            // everything but level 0 is reduced while level 0 is still being differentiated, so that the reduction left
+            // behind the last weight gradient (nothing else runs then) covers level 0 only
+            if (l == 1 && !getenv("MI_NO_SPLIT_REDUCE")) B.push_reduce_step("reduce gradients: encoder bucket, levels 1 and deeper");
         }
         B.push_reduce_step("reduce gradients: encoder bucket");
     }
