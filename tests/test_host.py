@@ -242,3 +242,41 @@ def test_conv2d_k16_fragment_reads_are_bank_conflict_free():
             lr, g = lane & 15, lane >> 4
             return (t * 16 + lr) * 32 + (g & 1) * 16
         assert _max_ways(waddr) == 1
+
+
+def _tr_b64_ways(addr_of_lane):
+    """ds_read_b64_tr_b16: 8 bytes per lane, bank = (addr / 4) % 64, the two 32-lane halves are served separately."""
+    worst = 1
+    for half in (range(0, 32), range(32, 64)):
+        banks = {}
+        for l in half:
+            a = addr_of_lane(l)
+            for b in ((a // 4) % 64, (a // 4 + 1) % 64):
+                banks.setdefault(b, set()).add(a)
+        worst = max(worst, max(len(v) for v in banks.values()))
+    return worst
+
+
+def test_wide_weight_gradient_transposed_reads_are_bank_conflict_free():
+    # unet_amd/csrc/wgrad3.hip: 128-byte pixel rows, 32-byte granule j of column x stored in slot j ^ ((x >> 1) & 3)
+    gswz = lambda x: (x >> 1) & 3
+    def pixel(lane, h):
+        lr, g = lane & 15, lane >> 4
+        return 16 * (g >> 1) + 8 * h + 4 * (g & 1) + (lr >> 2)
+    for h in range(2):
+        for blk in range(4):                                   # channel granule of the fragment
+            def faddr(lane, h=h, blk=blk):
+                v = pixel(lane, h)
+                return v * 128 + ((blk ^ gswz(v & 15)) * 32) + (lane & 3) * 8
+            assert _tr_b64_ways(faddr) == 1
+            for dy in range(3):
+                for dx in range(3):
+                    def saddr(lane, h=h, blk=blk, dy=dy, dx=dx):
+                        v = pixel(lane, h)
+                        r, c = v >> 4, v & 15
+                        return ((r + dy) * 18 + c + dx) * 128 + ((blk ^ gswz(c + dx)) * 32) + (lane & 3) * 8
+                    assert _tr_b64_ways(saddr) == 1, (h, blk, dy, dx)
+    # unpermuted rows: every second pixel row starts on the same banks
+    def plain(lane):
+        return pixel(lane, 0) * 128 + (lane & 3) * 8
+    assert _tr_b64_ways(plain) == 4

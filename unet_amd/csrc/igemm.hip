@@ -1293,7 +1293,9 @@ int launch_wgrad(int dtype, const WgradParams& p, hipStream_t st) {
         static const bool dma = !(getenv("MI_NO_WGRAD_DMA") && atoi(getenv("MI_NO_WGRAD_DMA")) != 0);
         if (dma) {
             WgradParams q = p;
-            const int r = launch_wgrad_dma(dtype, q, ff, sf, wf, wsn, st);
+            int r = launch_wgrad_thick(dtype, q, ff, sf, wf, wsn, st);
+            if (r <= 0) return r;
+            r = launch_wgrad_dma(dtype, q, ff, sf, wf, wsn, st);
             if (r <= 0) return r;
         }
     }

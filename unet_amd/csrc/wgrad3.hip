@@ -1,0 +1,242 @@
+// Weight gradient of the wide 2-D layers with asynchronous staging (gfx950, bf16).
+//
+// Same contract as wgrad_kernel (igemm.hip): partial[slab][tap][f][s] = sum over the slab's base pixels of
+// Fm[b][f] * Sm[b + off_tap][s], 3 x 3 taps, unit stride, 16 x 16 base-pixel tiles; a workgroup owns a 64 x 64 channel
+// block (four waves, 32 x 32 channels each, all nine taps in registers).  The register-staged kernel spends a third
+// of a tile's time computing addresses, issuing loads and writing LDS, holds 80 registers of prefetched data across
+// its multiply loop (372 registers: one workgroup per CU) and has nothing to overlap those phases with.  Here
+//  * a stage is half a tile (8 x 16 base pixels of the fixed operand, the 10 x 18 patch of the shifted one: 39 KB),
+//    two stages per workgroup, two workgroups per CU;
+//  * both operands go global -> LDS by global_load_lds (no registers in between), the next stage lands while the
+//    current one is multiplied; the per-lane source offsets are linear in the instruction number (fixed operand) or
+//    six precomputed values (patch), so no address arithmetic remains in the stage loop;
+//  * LDS rows are unpadded 128-byte pixel rows whose 32-byte granules are permuted by the pixel's column
+//    (granule j of column x sits in slot j ^ ((x >> 1) & 3)): a transposed read of a 32-lane half touches 8
+//    consecutive pixels, whose rows start on alternating bank halves; the permutation puts the four rows of a half
+//    on four different bank octets.  The DMA applies it to the source address;
+//  * every fragment address is one per-lane register plus an immediate (k-step, tap row), 16 registers in all.
+#include "common.h"
+#include "kparams.h"
+
+namespace {
+
+static __device__ __align__(256) unsigned char g_zero_page_t[256];
+
+__device__ __forceinline__ void dma16t(const char* gsrc, char* lds_base) {
+    // inline assembly: the compiler would drain every LDS-DMA it knows of in front of the next LDS read
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+
+__device__ __forceinline__ int gswz(int x) { return (x >> 1) & 3; }
+
+__global__ __launch_bounds__(256, 2) void wgrad_thick_kernel(const WgradParams p) {
+    constexpr int ROWB = 128;                        // 64 bf16 channels per LDS row, both operands
+    constexpr int PD = 18;
+    constexpr int FPX = 128, SPX = 10 * PD;          // pixels per stage
+    constexpr int NIF = FPX / 8, NIS = (SPX + 7) / 8;  // DMA wave-instructions per stage: 16 and 23 (8 pixels each)
+    constexpr int FBYTES = NIF * 1024, SBYTES = NIS * 1024;
+    constexpr int SLOT = FBYTES + SBYTES;
+    constexpr int NUF = NIF / 4, NUS = (NIS + 3) / 4;  // per wave: 4 and 6
+    constexpr int NT = 9;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, g = lane >> 4;
+    const int ws = wave & 1, wf = wave >> 1;
+    const int fb0 = blockIdx.y * 64, sb0 = blockIdx.z * 64;
+    const int H = p.bd[1], W = p.bd[2];              // unit stride: both operands have the base grid's extent
+
+    v4f acc[NT][2][2];
+    v4f accb[2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[t][a][b] = v4f{0.f, 0.f, 0.f, 0.f};
+    accb[0] = v4f{0.f, 0.f, 0.f, 0.f}; accb[1] = v4f{0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = (ws == 0) && (blockIdx.z == 0);
+
+    const char* fsrc; int fpitch, fcoff;
+    if (fb0 < p.f0_c) { fsrc = p.f0; fpitch = p.f0_pitch; fcoff = p.f0_coff + fb0; }
+    else { fsrc = p.f1; fpitch = p.f1_pitch; fcoff = p.f1_coff + fb0 - p.f0_c; }
+    const int fpb = fpitch * 2, spb = p.s_pitch * 2;
+    const char* const fbase = fsrc + (size_t)fcoff * 2;
+    const char* const sbase = p.s + (size_t)(p.s_coff + sb0) * 2;
+    const char* const zero = reinterpret_cast<const char*>(g_zero_page_t) + (lane & 7) * 16;
+
+    // ---- per-lane DMA constants ------------------------------------------------------------------------------------
+    // eight lanes fill one 128-byte row; LDS slot sl of the row takes source chunk (((sl >> 1) ^ gswz(column)) << 1) | (sl & 1)
+    const int sl = lane & 7;
+    const int f_col = 8 * (wave & 1) + (lane >> 3);  // instruction wave + 4u: stage row 2u + (wave >> 1), this column
+    const int f_row0 = wave >> 1;
+    const int f_off0 = (f_row0 * W + f_col) * fpb + ((((sl >> 1) ^ gswz(f_col)) << 1) | (sl & 1)) * 16;
+    const int f_ustep = 2 * W * fpb;
+    int s_off[NUS], s_yx[NUS];
+#pragma unroll
+    for (int u = 0; u < NUS; ++u) {
+        const int i = wave + 4 * u;
+        const int ps = i * 8 + (lane >> 3);
+        s_off[u] = 0; s_yx[u] = -1;
+        if (i < NIS && ps < SPX) {
+            const int py = ps / PD, px = ps - py * PD;
+            s_off[u] = (py * W + px) * spb + ((((sl >> 1) ^ gswz(px)) << 1) | (sl & 1)) * 16;
+            s_yx[u] = (py << 8) | px;
+        }
+    }
+
+    const int tiles_per_img = p.ntile[1] * p.ntile[2];
+    auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)d) + 1u; };
+    auto fdiv = [](int n, unsigned mg) { return mg ? (int)__umulhi((unsigned)n, mg) : n; };
+    const unsigned mg_img = magic(tiles_per_img), mg_x = magic(p.ntile[2]);
+
+    // stage j of this workgroup: half (j & 1) of tile blockIdx.x + (j >> 1) * nsplit, in slot j & 1
+    auto issue_stage = [&](int j) {
+        const int tile = blockIdx.x + (j >> 1) * p.nsplit;
+        const int img = fdiv(tile, mg_img);
+        const int tr = tile - img * tiles_per_img;
+        const int tyi = fdiv(tr, mg_x);
+        const int txi = tr - tyi * p.ntile[2];
+        const int by0 = (tyi << 4) + 8 * (j & 1), bx0 = txi << 4;
+        char* dstF = smem + (j & 1) * SLOT;
+        char* dstS = dstF + FBYTES;
+        {
+            const char* fb = fbase + (((long long)img * H + by0) * W + bx0) * fpb;
+            const bool colok = bx0 + f_col < W;
+#pragma unroll
+            for (int u = 0; u < NUF; ++u) {
+                const bool ok = colok && by0 + f_row0 + 2 * u < H;
+                dma16t(ok ? fb + f_off0 + u * f_ustep : zero, dstF + (wave + 4 * u) * 1024);
+            }
+        }
+        {
+            const int iy0 = by0 - 1, ix0 = bx0 - 1;
+            const char* sb = sbase + (((long long)img * H + iy0) * W + ix0) * spb;
+#pragma unroll
+            for (int u = 0; u < NUS; ++u) {
+                if (wave + 4 * u < NIS) {
+                    const bool ok = s_yx[u] >= 0 && (unsigned)(iy0 + (s_yx[u] >> 8)) < (unsigned)H && (unsigned)(ix0 + (s_yx[u] & 255)) < (unsigned)W;
+                    dma16t(ok ? sb + s_off[u] : zero, dstS + (wave + 4 * u) * 1024);
+                }
+            }
+        }
+    };
+
+    // ---- per-lane fragment addresses ---------------------------------------------------------------------------------
+    // contraction slot 8 g + 4 h + q of a k-step (32 pixels = two 16-pixel rows of the stage) takes pixel
+    // v = 16 (g / 2) + 8 h + 4 (g % 2) + q: a 32-lane half reads 8 consecutive pixels of one row
+    const int q = lr >> 2, pp = lr & 3;
+    int fa0[2][2], sa0[2][3][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int v = 16 * (g >> 1) + 8 * h + 4 * (g & 1) + q;
+        const int r = v >> 4, c = v & 15;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) fa0[h][a] = v * ROWB + (((wf * 2 + a) ^ gswz(c)) * 32) + pp * 8;
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) sa0[h][d][b] = (r * PD + c + d) * ROWB + (((ws * 2 + b) ^ gswz(c + d)) * 32) + pp * 8 + FBYTES;
+    }
+
+    const int ntw = p.tiles_total > (int)blockIdx.x ? (p.tiles_total - 1 - (int)blockIdx.x) / p.nsplit + 1 : 0;
+    const int nstage = 2 * ntw;
+    if (nstage > 0) issue_stage(0);
+    for (int j = 0; j < nstage; ++j) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                // stage j has landed everywhere, stage j - 1 has been consumed
+        asm volatile("" ::: "memory");
+        if (j + 1 < nstage) issue_stage(j + 1);
+        const char* sm = smem + (j & 1) * SLOT;
+#pragma unroll 1
+        for (int ks = 0; ks < 4; ++ks) {
+            uint4 afr[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(sm + fa0[0][a] + ks * 32 * ROWB));
+                v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(sm + fa0[1][a] + ks * 32 * ROWB));
+                v8s f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                afr[a] = __builtin_bit_cast(uint4, f);
+            }
+            if (do_bias) {
+                const uint4 ones = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+                    accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, afr[a]), __builtin_bit_cast(v8bf, ones), accb[a], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int dy = t / 3, dx = t % 3;
+                uint4 bfr[2];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(sm + sa0[0][dx][b] + (2 * ks + dy) * PD * ROWB));
+                    v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(sm + sa0[1][dx][b] + (2 * ks + dy) * PD * ROWB));
+                    v8s f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    bfr[b] = __builtin_bit_cast(uint4, f);
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[t][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, afr[a]), __builtin_bit_cast(v8bf, bfr[b]), acc[t][a][b], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- one slab per workgroup ----------------------------------------------------------------------------------------
+    const size_t slab = (size_t)blockIdx.x;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const size_t tbase = (slab * p.ntaps_total + t) * p.F;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int f = fb0 + (wf * 2 + a) * 16 + 4 * g + j;
+                    const int s = sb0 + (ws * 2 + b) * 16 + lr;
+                    p.partial[(tbase + f) * p.S + s] = acc[t][a][b][j];
+                }
+    }
+    if (do_bias && lr == 0) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) p.partial_bias[slab * p.F + fb0 + (wf * 2 + a) * 16 + 4 * g + j] = accb[a][j];
+    }
+}
+
+}  // namespace
+
+// Returns 0 when launched, 1 when this kernel does not serve the shape (the caller falls back), < 0 on error.
+int launch_wgrad_thick(int dtype, const WgradParams& p, int ff, int sf, int wf, int wsn, hipStream_t st) {
+    static const bool on = getenv("MI_NO_WGRAD_THICK") == nullptr;
+    if (!on || !dtype) return 1;
+    if (ff != 2 || sf != 2 || wf != 2 || wsn != 2) return 1;
+    if (p.ntaps_total != 9 || p.ntapg != 1 || p.ss != 1) return 1;
+    if (p.bd[0] != 1 || p.tlog[0] != 0 || p.tlog[1] != 4 || p.tlog[2] != 4 || p.pd[1] != 18 || p.pd[2] != 18) return 1;
+    if (p.omin[1] != -1 || p.omin[2] != -1) return 1;
+    for (int t = 0; t < 9; ++t)
+        if (p.tap_off[t] != (t / 3) * 18 + t % 3) return 1;
+    if (p.F % 64 || p.S % 64 || (p.f0_c < p.F && p.f0_c % 64)) return 1;
+    if (p.sd[1] != p.bd[1] || p.sd[2] != p.bd[2] || p.bd[1] > 255 * 16 || p.bd[2] > 255 * 16) return 1;
+    if ((long long)p.bd[1] * p.bd[2] * (p.s_pitch > p.f0_pitch ? p.s_pitch : p.f0_pitch) * 2 >= (1ll << 30)) return 1;
+    constexpr size_t lds = 2 * (16 + 23) * 1024;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_thick_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { mi_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return -2; }
+        attr_done = true;
+    }
+    dim3 grid(p.nsplit, p.F / 64, p.S / 64);
+    hipLaunchKernelGGL(wgrad_thick_kernel, grid, dim3(256), lds, st, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { mi_set_error(std::string("wgrad_thick launch: ") + hipGetErrorString(e)); return -2; }
+    return 0;
+}
