@@ -212,12 +212,311 @@ __global__ __launch_bounds__(256, 2) void wgrad_thick_kernel(const WgradParams p
     }
 }
 
+// ---- the same for gather stride 2 (stride-2 convolution, transposed convolution), 64 x 32 channel blocks ----------------
+// Base pixel b meets shifted pixels 2 b - 1 + k.  A tap reads one polyphase component of the shifted operand
+// (component (ry, rx) = pixels (2 i - ry, 2 j - rx)), and inside a component the gather has unit stride, so the
+// fragment reads look like the unit-stride kernel's.  A half tile is multiplied in three sub-stages that share its
+// fixed-operand image: components (0,0) + (0,1) (taps (1,1); (1,0) (1,2)), (1,0) (taps (0,1) (2,1)) and (1,1) (taps
+// (0,0) (0,2) (2,0) (2,2)); a component patch is 9 x 17 pixels of 64 bytes (32 channels), staged by ten DMA
+// instructions whose source addresses step two pixels.  Fixed-operand images and component patches are each
+// double-buffered (72 KB: two workgroups per CU).  Four waves = two 32-channel halves of the fixed operand x two
+// halves of the k-steps; the k-halves are added through LDS at the end, nine taps in two rounds.
+__device__ __forceinline__ int gswz64(int x) { return (x >> 2) & 1; }
+
+__global__ __launch_bounds__(256, 2) void wgrad_thick_s2_kernel(const WgradParams p) {
+    constexpr int ROWF = 128, ROWS = 64;
+    constexpr int PD = 17, CPX = 9 * PD;             // component patch: 153 pixels
+    constexpr int NIF = 16, NIC = (CPX + 15) / 16;   // DMA wave-instructions: fixed image (8 pixels each), component (16 pixels each): 10
+    constexpr int FBYTES = NIF * 1024, CBYTES = NIC * 1024;
+    constexpr int NUF = NIF / 4, NUC = (NIC + 3) / 4;  // per wave: 4 and 3
+    constexpr int NT = 9;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    char* const smF = smem;                          // two fixed-operand images
+    char* const smS = smem + 2 * FBYTES;             // ring of four component patches
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, g = lane >> 4;
+    const int wf = wave & 1, wk = wave >> 1;
+    const int fb0 = blockIdx.y * 64, sb0 = blockIdx.z * 32;
+    const int H = p.bd[1], W = p.bd[2], HS = p.sd[1], WS = p.sd[2];
+
+    v4f acc[NT][2][2];
+    v4f accb[2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[t][a][b] = v4f{0.f, 0.f, 0.f, 0.f};
+    accb[0] = v4f{0.f, 0.f, 0.f, 0.f}; accb[1] = v4f{0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = blockIdx.z == 0;
+
+    const char* fsrc; int fpitch, fcoff;
+    if (fb0 < p.f0_c) { fsrc = p.f0; fpitch = p.f0_pitch; fcoff = p.f0_coff + fb0; }
+    else { fsrc = p.f1; fpitch = p.f1_pitch; fcoff = p.f1_coff + fb0 - p.f0_c; }
+    const int fpb = fpitch * 2, spb = p.s_pitch * 2;
+    const char* const fbase = fsrc + (size_t)fcoff * 2;
+    const char* const sbase = p.s + (size_t)(p.s_coff + sb0) * 2;
+    const char* const zero = reinterpret_cast<const char*>(g_zero_page_t) + (lane & 7) * 16;
+
+    // ---- per-lane DMA constants ------------------------------------------------------------------------------------
+    const int slf = lane & 7;
+    const int f_col = 8 * (wave & 1) + (lane >> 3);
+    const int f_row0 = wave >> 1;
+    const int f_off0 = (f_row0 * W + f_col) * fpb + ((((slf >> 1) ^ gswz(f_col)) << 1) | (slf & 1)) * 16;
+    const int f_ustep = 2 * W * fpb;
+    const int sls = lane & 3;                        // four lanes fill one 64-byte row
+    int c_off[NUC], c_yx[NUC];
+#pragma unroll
+    for (int u = 0; u < NUC; ++u) {
+        const int i = (wave + 4 * u) % NIC;
+        const int ps = i * 16 + (lane >> 2);
+        c_off[u] = 0; c_yx[u] = -1;
+        if (ps < CPX) {
+            const int py = ps / PD, px = ps - py * PD;
+            c_off[u] = (2 * py * WS + 2 * px) * spb + ((((sls >> 1) ^ gswz64(px)) << 1) | (sls & 1)) * 16;
+            c_yx[u] = (py << 8) | px;
+        }
+    }
+
+    const int tiles_per_img = p.ntile[1] * p.ntile[2];
+    auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)d) + 1u; };
+    auto fdiv = [](int n, unsigned mg) { return mg ? (int)__umulhi((unsigned)n, mg) : n; };
+    const unsigned mg_img = magic(tiles_per_img), mg_x = magic(p.ntile[2]);
+
+    // Sub-stage m = 4 * hs + k multiplies component k of half tile hs (half (hs & 1) of tile blockIdx.x + (hs >> 1) *
+    // nsplit); its patch lives in ring slot k, the half tile's fixed image (brought along with component 0) in image
+    // slot hs & 1.  Loads run three sub-stages ahead.
+    int q_m = 0, q_k = 0, q_hs = 0, q_img = 0, q_by0 = 0, q_bx0 = 0;
+    const int ntw = p.tiles_total > (int)blockIdx.x ? (p.tiles_total - 1 - (int)blockIdx.x) / p.nsplit + 1 : 0;
+    const int nhs = 2 * ntw, nsub = 4 * nhs;
+    auto issue_next = [&]() {
+        if (q_m < nsub) {
+            if (q_k == 0) {
+                const int tile = blockIdx.x + (q_hs >> 1) * p.nsplit;
+                q_img = fdiv(tile, mg_img);
+                const int tr = tile - q_img * tiles_per_img;
+                const int tyi = fdiv(tr, mg_x);
+                const int txi = tr - tyi * p.ntile[2];
+                q_by0 = (tyi << 4) + 8 * (q_hs & 1); q_bx0 = txi << 4;
+                char* dstF = smF + (q_hs & 1) * FBYTES;
+                const char* fb = fbase + (((long long)q_img * H + q_by0) * W + q_bx0) * fpb;
+                const bool colok = q_bx0 + f_col < W;
+#pragma unroll
+                for (int u = 0; u < NUF; ++u) {
+                    const bool ok = colok && q_by0 + f_row0 + 2 * u < H;
+                    dma16t(ok ? fb + f_off0 + u * f_ustep : zero, dstF + (wave + 4 * u) * 1024);
+                }
+            }
+            const int ry = q_k >> 1, rx = q_k & 1;
+            const int iy0 = 2 * q_by0 - ry, ix0 = 2 * q_bx0 - rx;
+            const char* sb = sbase + (((long long)q_img * HS + iy0) * WS + ix0) * spb;
+            char* dstS = smS + q_k * CBYTES;
+#pragma unroll
+            for (int u = 0; u < NUC; ++u) {
+                const int i = (wave + 4 * u) % NIC;      // past the end: a harmless repeat, so every wave issues NUC loads
+                const bool ok = c_yx[u] >= 0 && (unsigned)(iy0 + 2 * (c_yx[u] >> 8)) < (unsigned)HS && (unsigned)(ix0 + 2 * (c_yx[u] & 255)) < (unsigned)WS;
+                dma16t(ok ? sb + c_off[u] : zero, dstS + i * 1024);
+            }
+        }
+        ++q_m;
+        if (++q_k == 4) { q_k = 0; ++q_hs; }
+    };
+
+    // ---- per-lane fragment addresses ---------------------------------------------------------------------------------
+    const int q = lr >> 2, pp = lr & 3;
+    int fa0[2][2], sa0[2][2][2];                     // [half of the k-step][..]: fixed [fragment]; shifted [column offset][fragment]
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int v = 16 * (g >> 1) + 8 * h + 4 * (g & 1) + q;
+        const int r = v >> 4, c = v & 15;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) fa0[h][a] = v * ROWF + (((wf * 2 + a) ^ gswz(c)) * 32) + pp * 8;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) sa0[h][d][b] = (r * PD + c + d) * ROWS + ((b ^ gswz64(c + d)) * 32) + pp * 8;
+    }
+
+    // one tap: the two shifted-operand fragments of the component patch in ring slot CS at row / column offset
+    // (IY, IX), four MFMAs
+#define WG3_TAP(T, CS, IY, IX)                                                                                          \
+    do {                                                                                                                \
+        uint4 bfr_[2];                                                                                                  \
+        _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                                                 \
+            const char* base_ = smS + (CS) * CBYTES + (2 * ks + (IY)) * PD * ROWS;                                      \
+            v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(base_ + sa0[0][IX][b])); \
+            v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(base_ + sa0[1][IX][b])); \
+            v8s f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};                                           \
+            bfr_[b] = __builtin_bit_cast(uint4, f);                                                                     \
+        }                                                                                                               \
+        _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                                   \
+            _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                               \
+                acc[T][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, afr[a]), __builtin_bit_cast(v8bf, bfr_[b]), acc[T][a][b], 0, 0, 0); \
+    } while (0)
+    constexpr int LC = NUC, LF = NUC + NUF;          // this wave's loads of a sub-stage without / with the fixed image
+#pragma unroll
+    for (int j = 0; j < 3; ++j) issue_next();
+    for (int hs = 0; hs < nhs; ++hs) {
+        const char* sF = smF + (hs & 1) * FBYTES;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            // the loads of the next two sub-stages may stay in flight (the third is issued below)
+            const int rem = nsub - 1 - (4 * hs + k);
+            if (rem >= 2) {
+                if (k == 0 || k == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LC) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LC + LF) : "memory");
+            } else if (rem == 1) {
+                if (k == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LF) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LC) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();            // sub-stage 4 hs + k has landed everywhere, the one before has been consumed
+            asm volatile("" ::: "memory");
+            issue_next();
+#pragma unroll 1
+            for (int kk = 0; kk < 2; ++kk) {
+                const int ks = 2 * kk + wk;          // this wave's k-steps of the half tile
+                uint4 afr[2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(sF + fa0[0][a] + ks * 32 * ROWF));
+                    v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(sF + fa0[1][a] + ks * 32 * ROWF));
+                    v8s f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    afr[a] = __builtin_bit_cast(uint4, f);
+                }
+                if (k == 0) {
+                    if (do_bias) {
+                        const uint4 ones = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+                            accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, afr[a]), __builtin_bit_cast(v8bf, ones), accb[a], 0, 0, 0);
+                    }
+                    WG3_TAP(4, 0, 0, 0);             // component (0,0): tap (1,1)
+                } else if (k == 1) {
+                    WG3_TAP(3, 1, 0, 0);             // component (0,1): taps (1,0), (1,2)
+                    WG3_TAP(5, 1, 0, 1);
+                } else if (k == 2) {
+                    WG3_TAP(1, 2, 0, 0);             // component (1,0): taps (0,1), (2,1)
+                    WG3_TAP(7, 2, 1, 0);
+                } else {
+                    WG3_TAP(0, 3, 0, 0);             // component (1,1): taps (0,0), (0,2), (2,0), (2,2)
+                    WG3_TAP(2, 3, 0, 1);
+                    WG3_TAP(6, 3, 1, 0);
+                    WG3_TAP(8, 3, 1, 1);
+                }
+            }
+        }
+    }
+#undef WG3_TAP
+
+    // ---- add the two k-halves through LDS (taps 0..4, then taps 5..8 and the bias column), then one slab ---------------
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float* red = reinterpret_cast<float*>(smem);     // [wf][value][64 lanes]
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        const int t0 = round ? 5 : 0, t1 = round ? NT : 5;
+        __syncthreads();
+        if (wk == 1) {
+            float* mine = red + (size_t)wf * 88 * 64 + lane;
+            int v = 0;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (t >= t0 && t < t1) {
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) mine[(v++) * 64] = acc[t][a][b][j];
+                }
+            if (round == 1) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mine[(v++) * 64] = accb[a][j];
+            }
+        }
+        __syncthreads();
+        if (wk == 0) {
+            const float* theirs = red + (size_t)wf * 88 * 64 + lane;
+            int v = 0;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (t >= t0 && t < t1) {
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[t][a][b][j] += theirs[(v++) * 64];
+                }
+            if (round == 1) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) accb[a][j] += theirs[(v++) * 64];
+            }
+        }
+    }
+    if (wk == 0) {
+        const size_t slab = (size_t)blockIdx.x;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const size_t tbase = (slab * p.ntaps_total + t) * p.F;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int f = fb0 + (wf * 2 + a) * 16 + 4 * g + j;
+                        const int sc = sb0 + b * 16 + lr;
+                        p.partial[(tbase + f) * p.S + sc] = acc[t][a][b][j];
+                    }
+        }
+        if (do_bias && lr == 0) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) p.partial_bias[slab * p.F + fb0 + (wf * 2 + a) * 16 + 4 * g + j] = accb[a][j];
+        }
+    }
+}
+
 }  // namespace
 
 // Returns 0 when launched, 1 when this kernel does not serve the shape (the caller falls back), < 0 on error.
 int launch_wgrad_thick(int dtype, const WgradParams& p, int ff, int sf, int wf, int wsn, hipStream_t st) {
     static const bool on = getenv("MI_NO_WGRAD_THICK") == nullptr;
     if (!on || !dtype) return 1;
+    if (ff == 2 && sf == 2 && wf == 2 && wsn == 1 && p.ss == 2) {
+        // gather stride 2, 64 x 32 blocks
+        static const bool s2on = getenv("MI_NO_WGRAD_THICK_S2") == nullptr;
+        if (!s2on) return 1;
+        if (p.ntaps_total != 9 || p.ntapg != 1) return 1;
+        if (p.bd[0] != 1 || p.tlog[0] != 0 || p.tlog[1] != 4 || p.tlog[2] != 4 || p.pd[1] != 33 || p.pd[2] != 33) return 1;
+        if (p.omin[1] != -1 || p.omin[2] != -1) return 1;
+        for (int t = 0; t < 9; ++t)
+            if (p.tap_off[t] != (t / 3) * 33 + t % 3) return 1;
+        if (p.F % 64 || p.S % 32 || (p.f0_c < p.F && p.f0_c % 64)) return 1;
+        if (p.bd[1] > 127 * 16 || p.bd[2] > 127 * 16) return 1;
+        if ((long long)p.sd[1] * p.sd[2] * p.s_pitch * 2 >= (1ll << 30) || (long long)p.bd[1] * p.bd[2] * (p.f0_pitch > p.f1_pitch ? p.f0_pitch : p.f1_pitch) * 2 >= (1ll << 30)) return 1;
+        constexpr size_t lds2 = 2 * 16 * 1024 + 4 * 10 * 1024;
+        static bool attr2 = false;
+        if (!attr2) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_thick_s2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            if (e != hipSuccess) { mi_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return -2; }
+            attr2 = true;
+        }
+        dim3 grid2(p.nsplit, p.F / 64, p.S / 32);
+        hipLaunchKernelGGL(wgrad_thick_s2_kernel, grid2, dim3(256), lds2, st, p);
+        hipError_t e2 = hipGetLastError();
+        if (e2 != hipSuccess) { mi_set_error(std::string("wgrad_thick_s2 launch: ") + hipGetErrorString(e2)); return -2; }
+        return 0;
+    }
     if (ff != 2 || sf != 2 || wf != 2 || wsn != 2) return 1;
     if (p.ntaps_total != 9 || p.ntapg != 1 || p.ss != 1) return 1;
     if (p.bd[0] != 1 || p.tlog[0] != 0 || p.tlog[1] != 4 || p.tlog[2] != 4 || p.pd[1] != 18 || p.pd[2] != 18) return 1;
