@@ -1240,6 +1240,7 @@ static size_t wgrad_lds_for(int dtype, const WgradParams& p, int FB, int SB) {
 // Weight-gradient block shape: FB x SB channels per workgroup (fragments per wave and wave
 // arrangement follow), shrunk until the LDS images fit.
 void wgrad_config(int dtype, const WgradParams& p, int* ff, int* sf, int* wf, int* wsn) {
+    if (wgrad_thick_config(dtype, p, ff, sf, wf, wsn)) return;
     auto pick = [](int c, int maxblk) { int b = maxblk; while (b > 16 && c % b) b >>= 1; return b; };
     int maxb = dtype ? 64 : 32;
     if (const char* e = getenv("MI_WG_MAXB")) { const int v = atoi(e); if (v >= 16 && v < maxb) maxb = v; }
@@ -1284,7 +1285,9 @@ int launch_wgrad(int dtype, const WgradParams& p, hipStream_t st) {
     int ff, sf, wf, wsn;
     wgrad_config(dtype, p, &ff, &sf, &wf, &wsn);
     MI_CHECK(p.F % 16 == 0 && p.S % 16 == 0, "channel counts must be multiples of 16");
-    MI_CHECK(p.f0_c >= p.F || p.f0_c % (16 * ff * wf) == 0, "first-source channel count must be a multiple of the F block");
+    int tf, ts, twf, tws;
+    const bool thick = wgrad_thick_config(dtype, p, &tf, &ts, &twf, &tws);
+    MI_CHECK(thick || p.f0_c >= p.F || p.f0_c % (16 * ff * wf) == 0, "first-source channel count must be a multiple of the F block");
     MI_CHECK(p.tlog[0] + p.tlog[1] + p.tlog[2] == 8, "tile must hold 256 base pixels");
     MI_CHECK(wgrad_lds_for(dtype, p, 16 * ff * wf, 16 * sf * wsn) <= 160 * 1024, "LDS images do not fit");
     const int nt = p.ntaps_total / p.ntapg;

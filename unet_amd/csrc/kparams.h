@@ -149,6 +149,7 @@ bool conv2d_dma_enabled();
 void conv2d_dma_label(int dtype, const IgemmParams& p, char* buf, size_t n);   // step-table name of the kernel that serves p
 int launch_wgrad_dma(int dtype, const WgradParams& p, int ff, int sf, int wf, int wsn, hipStream_t st);   // 1: shape not served
 int launch_wgrad_thick(int dtype, const WgradParams& p, int ff, int sf, int wf, int wsn, hipStream_t st);   // wgrad3.hip; 1: shape not served
+bool wgrad_thick_config(int dtype, const WgradParams& p, int* ff, int* sf, int* wf, int* wsn);   // block shape wgrad3.hip wants for p
 int launch_reduce(const ReduceTable& tab, int total_blocks, hipStream_t st);   // total_blocks: sum of the descriptors' nblk
 int reduce_blocks_for(int total);
 int launch_pack(int dtype, const PackTable& tab, int total_blocks, hipStream_t st);

@@ -61,11 +61,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_thick_kernel(const WgradParams p
     accb[0] = v4f{0.f, 0.f, 0.f, 0.f}; accb[1] = v4f{0.f, 0.f, 0.f, 0.f};
     const bool do_bias = (ws == 0) && (blockIdx.z == 0);
 
-    const char* fsrc; int fpitch, fcoff;
-    if (fb0 < p.f0_c) { fsrc = p.f0; fpitch = p.f0_pitch; fcoff = p.f0_coff + fb0; }
-    else { fsrc = p.f1; fpitch = p.f1_pitch; fcoff = p.f1_coff + fb0 - p.f0_c; }
-    const int fpb = fpitch * 2, spb = p.s_pitch * 2;
-    const char* const fbase = fsrc + (size_t)fcoff * 2;
+    const int spb = p.s_pitch * 2;
     const char* const sbase = p.s + (size_t)(p.s_coff + sb0) * 2;
     const char* const zero = reinterpret_cast<const char*>(g_zero_page_t) + (lane & 7) * 16;
 
@@ -74,7 +70,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_thick_kernel(const WgradParams p
     const int sl = lane & 7;
     const int f_col = 8 * (wave & 1) + (lane >> 3);  // instruction wave + 4u: stage row 2u + (wave >> 1), this column
     const int f_row0 = wave >> 1;
-    const int f_off0 = (f_row0 * W + f_col) * fpb + ((((sl >> 1) ^ gswz(f_col)) << 1) | (sl & 1)) * 16;
+    // the lane's 8 channels come from the first or the second source tensor of the fixed operand (a block may span both)
+    const int f_ch = fb0 + ((((sl >> 1) ^ gswz(f_col)) << 1) | (sl & 1)) * 8;
+    const bool f_first = f_ch < p.f0_c;
+    const int fpb = (f_first ? p.f0_pitch : p.f1_pitch) * 2;
+    const char* const fbase = f_first ? p.f0 + (size_t)(p.f0_coff + f_ch) * 2 : p.f1 + (size_t)(p.f1_coff + f_ch - p.f0_c) * 2;
+    const int f_off0 = (f_row0 * W + f_col) * fpb;
     const int f_ustep = 2 * W * fpb;
     int s_off[NUS], s_yx[NUS];
 #pragma unroll
@@ -223,10 +224,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_thick_kernel(const WgradParams p
 // halves of the k-steps; the k-halves are added through LDS at the end, nine taps in two rounds.
 __device__ __forceinline__ int gswz64(int x) { return (x >> 2) & 1; }
 
+template <int SF>   // 16-channel fragments of the shifted operand per workgroup: 2 (64-byte rows) or 1 (32-byte rows, unpermuted)
 __global__ __launch_bounds__(256, 2) void wgrad_thick_s2_kernel(const WgradParams p) {
-    constexpr int ROWF = 128, ROWS = 64;
+    constexpr int ROWF = 128, ROWS = 32 * SF;
     constexpr int PD = 17, CPX = 9 * PD;             // component patch: 153 pixels
-    constexpr int NIF = 16, NIC = (CPX + 15) / 16;   // DMA wave-instructions: fixed image (8 pixels each), component (16 pixels each): 10
+    constexpr int LPP = ROWS / 16, PPI = 64 / LPP;   // lanes per patch pixel, pixels per DMA instruction
+    constexpr int NIF = 16, NIC = (CPX + PPI - 1) / PPI;   // DMA wave-instructions: fixed image (8 pixels each), component: 10 or 5
     constexpr int FBYTES = NIF * 1024, CBYTES = NIC * 1024;
     constexpr int NUF = NIF / 4, NUC = (NIC + 3) / 4;  // per wave: 4 and 3
     constexpr int NT = 9;
@@ -238,25 +241,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_thick_s2_kernel(const WgradParam
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, g = lane >> 4;
     const int wf = wave & 1, wk = wave >> 1;
-    const int fb0 = blockIdx.y * 64, sb0 = blockIdx.z * 32;
+    const int fb0 = blockIdx.y * 64, sb0 = blockIdx.z * 16 * SF;
     const int H = p.bd[1], W = p.bd[2], HS = p.sd[1], WS = p.sd[2];
 
-    v4f acc[NT][2][2];
+    v4f acc[NT][2][SF];
     v4f accb[2];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) acc[t][a][b] = v4f{0.f, 0.f, 0.f, 0.f};
+            for (int b = 0; b < SF; ++b) acc[t][a][b] = v4f{0.f, 0.f, 0.f, 0.f};
     accb[0] = v4f{0.f, 0.f, 0.f, 0.f}; accb[1] = v4f{0.f, 0.f, 0.f, 0.f};
     const bool do_bias = blockIdx.z == 0;
 
-    const char* fsrc; int fpitch, fcoff;
-    if (fb0 < p.f0_c) { fsrc = p.f0; fpitch = p.f0_pitch; fcoff = p.f0_coff + fb0; }
-    else { fsrc = p.f1; fpitch = p.f1_pitch; fcoff = p.f1_coff + fb0 - p.f0_c; }
-    const int fpb = fpitch * 2, spb = p.s_pitch * 2;
-    const char* const fbase = fsrc + (size_t)fcoff * 2;
+    const int spb = p.s_pitch * 2;
     const char* const sbase = p.s + (size_t)(p.s_coff + sb0) * 2;
     const char* const zero = reinterpret_cast<const char*>(g_zero_page_t) + (lane & 7) * 16;
 
@@ -264,18 +263,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_thick_s2_kernel(const WgradParam
     const int slf = lane & 7;
     const int f_col = 8 * (wave & 1) + (lane >> 3);
     const int f_row0 = wave >> 1;
-    const int f_off0 = (f_row0 * W + f_col) * fpb + ((((slf >> 1) ^ gswz(f_col)) << 1) | (slf & 1)) * 16;
+    const int f_ch = fb0 + ((((slf >> 1) ^ gswz(f_col)) << 1) | (slf & 1)) * 8;
+    const bool f_first = f_ch < p.f0_c;
+    const int fpb = (f_first ? p.f0_pitch : p.f1_pitch) * 2;
+    const char* const fbase = f_first ? p.f0 + (size_t)(p.f0_coff + f_ch) * 2 : p.f1 + (size_t)(p.f1_coff + f_ch - p.f0_c) * 2;
+    const int f_off0 = (f_row0 * W + f_col) * fpb;
     const int f_ustep = 2 * W * fpb;
-    const int sls = lane & 3;                        // four lanes fill one 64-byte row
+    const int sls = lane % LPP;                      // LPP lanes fill one row
     int c_off[NUC], c_yx[NUC];
 #pragma unroll
     for (int u = 0; u < NUC; ++u) {
         const int i = (wave + 4 * u) % NIC;
-        const int ps = i * 16 + (lane >> 2);
+        const int ps = i * PPI + lane / LPP;
         c_off[u] = 0; c_yx[u] = -1;
         if (ps < CPX) {
             const int py = ps / PD, px = ps - py * PD;
-            c_off[u] = (2 * py * WS + 2 * px) * spb + ((((sls >> 1) ^ gswz64(px)) << 1) | (sls & 1)) * 16;
+            c_off[u] = (2 * py * WS + 2 * px) * spb + (SF == 2 ? ((((sls >> 1) ^ gswz64(px)) << 1) | (sls & 1)) : sls) * 16;
             c_yx[u] = (py << 8) | px;
         }
     }
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_thick_s2_kernel(const WgradParam
 
     // ---- per-lane fragment addresses ---------------------------------------------------------------------------------
     const int q = lr >> 2, pp = lr & 3;
-    int fa0[2][2], sa0[2][2][2];                     // [half of the k-step][..]: fixed [fragment]; shifted [column offset][fragment]
+    int fa0[2][2], sa0[2][2][SF];                     // [half of the k-step][..]: fixed [fragment]; shifted [column offset][fragment]
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int v = 16 * (g >> 1) + 8 * h + 4 * (g & 1) + q;
@@ -336,15 +339,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_thick_s2_kernel(const WgradParam
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) sa0[h][d][b] = (r * PD + c + d) * ROWS + ((b ^ gswz64(c + d)) * 32) + pp * 8;
+            for (int b = 0; b < SF; ++b) sa0[h][d][b] = (r * PD + c + d) * ROWS + (SF == 2 ? ((b ^ gswz64(c + d)) * 32) : 0) + pp * 8;
     }
 
     // one tap: the two shifted-operand fragments of the component patch in ring slot CS at row / column offset
     // (IY, IX), four MFMAs
 #define WG3_TAP(T, CS, IY, IX)                                                                                          \
     do {                                                                                                                \
-        uint4 bfr_[2];                                                                                                  \
-        _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                                                 \
+        uint4 bfr_[SF];                                                                                                 \
+        _Pragma("unroll") for (int b = 0; b < SF; ++b) {                                                                 \
             const char* base_ = smS + (CS) * CBYTES + (2 * ks + (IY)) * PD * ROWS;                                      \
             v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(base_ + sa0[0][IX][b])); \
             v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(base_ + sa0[1][IX][b])); \
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_thick_s2_kernel(const WgradParam
             bfr_[b] = __builtin_bit_cast(uint4, f);                                                                     \
         }                                                                                                               \
         _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                                   \
-            _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                               \
+            _Pragma("unroll") for (int b = 0; b < SF; ++b)                                                              \
                 acc[T][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, afr[a]), __builtin_bit_cast(v8bf, bfr_[b]), acc[T][a][b], 0, 0, 0); \
     } while (0)
     constexpr int LC = NUC, LF = NUC + NUF;          // this wave's loads of a sub-stage without / with the fixed image
@@ -420,7 +423,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_thick_s2_kernel(const WgradParam
         const int t0 = round ? 5 : 0, t1 = round ? NT : 5;
         __syncthreads();
         if (wk == 1) {
-            float* mine = red + (size_t)wf * 88 * 64 + lane;
+            float* mine = red + (size_t)wf * (40 * SF + 8) * 64 + lane;
             int v = 0;
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_thick_s2_kernel(const WgradParam
 #pragma unroll
                     for (int a = 0; a < 2; ++a)
 #pragma unroll
-                        for (int b = 0; b < 2; ++b)
+                        for (int b = 0; b < SF; ++b)
 #pragma unroll
                             for (int j = 0; j < 4; ++j) mine[(v++) * 64] = acc[t][a][b][j];
                 }
@@ -441,7 +444,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_thick_s2_kernel(const WgradParam
         }
         __syncthreads();
         if (wk == 0) {
-            const float* theirs = red + (size_t)wf * 88 * 64 + lane;
+            const float* theirs = red + (size_t)wf * (40 * SF + 8) * 64 + lane;
             int v = 0;
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -449,7 +452,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_thick_s2_kernel(const WgradParam
 #pragma unroll
                     for (int a = 0; a < 2; ++a)
 #pragma unroll
-                        for (int b = 0; b < 2; ++b)
+                        for (int b = 0; b < SF; ++b)
 #pragma unroll
                             for (int j = 0; j < 4; ++j) acc[t][a][b][j] += theirs[(v++) * 64];
                 }
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_thick_s2_kernel(const WgradParam
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
+                for (int b = 0; b < SF; ++b)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int f = fb0 + (wf * 2 + a) * 16 + 4 * g + j;
@@ -488,44 +491,65 @@ __global__ __launch_bounds__(256, 2) void wgrad_thick_s2_kernel(const WgradParam
 
 }  // namespace
 
-// Returns 0 when launched, 1 when this kernel does not serve the shape (the caller falls back), < 0 on error.
-int launch_wgrad_thick(int dtype, const WgradParams& p, int ff, int sf, int wf, int wsn, hipStream_t st) {
-    static const bool on = getenv("MI_NO_WGRAD_THICK") == nullptr;
-    if (!on || !dtype) return 1;
-    if (ff == 2 && sf == 2 && wf == 2 && wsn == 1 && p.ss == 2) {
-        // gather stride 2, 64 x 32 blocks
-        static const bool s2on = getenv("MI_NO_WGRAD_THICK_S2") == nullptr;
-        if (!s2on) return 1;
-        if (p.ntaps_total != 9 || p.ntapg != 1) return 1;
-        if (p.bd[0] != 1 || p.tlog[0] != 0 || p.tlog[1] != 4 || p.tlog[2] != 4 || p.pd[1] != 33 || p.pd[2] != 33) return 1;
-        if (p.omin[1] != -1 || p.omin[2] != -1) return 1;
+// Which kernel of this file serves `p`: 0 none, 1 unit stride (64 x 64 blocks), 2 / 3 gather stride 2 with 64 x 32 /
+// 64 x 16 blocks.  Every shape condition the kernels rely on is checked here and nowhere else.
+static int thick_kind(int dtype, const WgradParams& p) {
+    static const bool on = getenv("MI_NO_WGRAD_THICK") == nullptr && !(getenv("MI_NO_WGRAD_DMA") && atoi(getenv("MI_NO_WGRAD_DMA")) != 0);
+    static const bool s2on = getenv("MI_NO_WGRAD_THICK_S2") == nullptr;
+    if (!on || !dtype || p.ntaps_total != 9 || p.ntapg != 1) return 0;
+    if (p.bd[0] != 1 || p.tlog[0] != 0 || p.tlog[1] != 4 || p.tlog[2] != 4 || p.omin[1] != -1 || p.omin[2] != -1) return 0;
+    if (p.F % 64 || (p.f0_c < p.F && p.f0_c % 8)) return 0;
+    const long long fpm = p.f0_c < p.F && p.f1_pitch > p.f0_pitch ? p.f1_pitch : p.f0_pitch;
+    if (p.ss == 1) {
+        if (p.pd[1] != 18 || p.pd[2] != 18 || p.S % 64) return 0;
         for (int t = 0; t < 9; ++t)
-            if (p.tap_off[t] != (t / 3) * 33 + t % 3) return 1;
-        if (p.F % 64 || p.S % 32 || (p.f0_c < p.F && p.f0_c % 64)) return 1;
-        if (p.bd[1] > 127 * 16 || p.bd[2] > 127 * 16) return 1;
-        if ((long long)p.sd[1] * p.sd[2] * p.s_pitch * 2 >= (1ll << 30) || (long long)p.bd[1] * p.bd[2] * (p.f0_pitch > p.f1_pitch ? p.f0_pitch : p.f1_pitch) * 2 >= (1ll << 30)) return 1;
-        constexpr size_t lds2 = 2 * 16 * 1024 + 4 * 10 * 1024;
-        static bool attr2 = false;
-        if (!attr2) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_thick_s2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            if (p.tap_off[t] != (t / 3) * 18 + t % 3) return 0;
+        if (p.sd[1] != p.bd[1] || p.sd[2] != p.bd[2] || p.bd[1] > 255 * 16 || p.bd[2] > 255 * 16) return 0;
+        if ((long long)p.bd[1] * p.bd[2] * (p.s_pitch > fpm ? p.s_pitch : fpm) * 2 >= (1ll << 30)) return 0;
+        return 1;
+    }
+    if (p.ss == 2 && s2on) {
+        if (p.pd[1] != 33 || p.pd[2] != 33 || p.S % 16) return 0;
+        for (int t = 0; t < 9; ++t)
+            if (p.tap_off[t] != (t / 3) * 33 + t % 3) return 0;
+        if (p.bd[1] > 127 * 16 || p.bd[2] > 127 * 16) return 0;
+        if ((long long)p.sd[1] * p.sd[2] * p.s_pitch * 2 >= (1ll << 30) || (long long)p.bd[1] * p.bd[2] * fpm * 2 >= (1ll << 30)) return 0;
+        return p.S % 32 == 0 ? 2 : 3;
+    }
+    return 0;
+}
+
+// Block shape (fragments per wave, waves per side) under which the kernels of this file serve `p`, or false.  The
+// split policy and the slab count follow the block shape, so wgrad_config asks here first.
+bool wgrad_thick_config(int dtype, const WgradParams& p, int* ff, int* sf, int* wf, int* wsn) {
+    const int k = thick_kind(dtype, p);
+    if (!k) return false;
+    *ff = 2; *wf = 2;
+    *sf = k == 3 ? 1 : 2;
+    *wsn = k == 1 ? 2 : 1;
+    return true;
+}
+
+// Returns 0 when launched, 1 when this file does not serve the shape (the caller falls back), < 0 on error.
+int launch_wgrad_thick(int dtype, const WgradParams& p, int ff, int sf, int wf, int wsn, hipStream_t st) {
+    int cf, cs, cwf, cws;
+    if (!wgrad_thick_config(dtype, p, &cf, &cs, &cwf, &cws)) return 1;
+    if (cf != ff || cs != sf || cwf != wf || cws != wsn) { mi_set_error("wgrad_thick: block shape differs from the one the slabs were sized for"); return -2; }
+    if (p.ss == 2) {
+        const size_t lds2 = 2 * 16 * 1024 + 4 * (sf == 2 ? 10 : 5) * 1024;
+        auto kern2 = sf == 2 ? wgrad_thick_s2_kernel<2> : wgrad_thick_s2_kernel<1>;
+        static bool attr2[2] = {false, false};
+        if (!attr2[sf - 1]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
             if (e != hipSuccess) { mi_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return -2; }
-            attr2 = true;
+            attr2[sf - 1] = true;
         }
-        dim3 grid2(p.nsplit, p.F / 64, p.S / 32);
-        hipLaunchKernelGGL(wgrad_thick_s2_kernel, grid2, dim3(256), lds2, st, p);
+        dim3 grid2(p.nsplit, p.F / 64, p.S / (16 * sf));
+        hipLaunchKernelGGL(kern2, grid2, dim3(256), lds2, st, p);
         hipError_t e2 = hipGetLastError();
         if (e2 != hipSuccess) { mi_set_error(std::string("wgrad_thick_s2 launch: ") + hipGetErrorString(e2)); return -2; }
         return 0;
     }
-    if (ff != 2 || sf != 2 || wf != 2 || wsn != 2) return 1;
-    if (p.ntaps_total != 9 || p.ntapg != 1 || p.ss != 1) return 1;
-    if (p.bd[0] != 1 || p.tlog[0] != 0 || p.tlog[1] != 4 || p.tlog[2] != 4 || p.pd[1] != 18 || p.pd[2] != 18) return 1;
-    if (p.omin[1] != -1 || p.omin[2] != -1) return 1;
-    for (int t = 0; t < 9; ++t)
-        if (p.tap_off[t] != (t / 3) * 18 + t % 3) return 1;
-    if (p.F % 64 || p.S % 64 || (p.f0_c < p.F && p.f0_c % 64)) return 1;
-    if (p.sd[1] != p.bd[1] || p.sd[2] != p.bd[2] || p.bd[1] > 255 * 16 || p.bd[2] > 255 * 16) return 1;
-    if ((long long)p.bd[1] * p.bd[2] * (p.s_pitch > p.f0_pitch ? p.s_pitch : p.f0_pitch) * 2 >= (1ll << 30)) return 1;
     constexpr size_t lds = 2 * (16 + 23) * 1024;
     static bool attr_done = false;
     if (!attr_done) {
