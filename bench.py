@@ -427,7 +427,7 @@ def main():
                         us = 1e3 * s["total_ms"] / s["launches"]
                         tf = s["work"] / (us * 1e-6) / 1e12 if s["work_is_flops"] else 0.0
                         log(f"  {'bwd' if backward else 'fwd'} {s['layer']:48s} {s['kernel']:34s} {us:9.2f} us {tf:8.1f} TF/s {s['bytes'] / (us * 1e-6) / 1e9:9.1f} GB/s")
-        conv = {k: r for k, r in rows.items() if r["flops"] > 0 and ("igemm" in k or "conv2d_" in k or "wgrad_kernel" in k)}
+        conv = {k: r for k, r in rows.items() if r["flops"] > 0 and ("igemm" in k or "conv2d_" in k or "wgrad_kernel" in k or "wgrad_thick" in k or "wgrad_thin" in k)}
         conv_s = sum(r["ms"] for r in conv.values()) / 1e3
         conv_f = sum(r["flops"] for r in conv.values())
         out["mfma_util"] = round(conv_f / conv_s / MFMA_BF16_PEAK, 4) if conv_s else None

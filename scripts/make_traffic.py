@@ -14,7 +14,7 @@ def label(name: str) -> str:
     m = re.search(r"(\w+)<(BF16|F32)((?:, [\w-]+)*)>", name)
     base = re.sub(r"^void |\(anonymous namespace\)::", "", name).split("(")[0]
     if not m:
-        k16 = re.match(r"(conv2d_s?2?k16_kernel)<(\d+)>", base)
+        k16 = re.match(r"(conv2d_s?2?k16_kernel|wgrad_thick_s2_kernel|wgrad_thin_kernel)<(\d+)(?:, \d+)*>", base)
         if k16:
             return f"{k16.group(1)}<{k16.group(2)}>"
         base = re.sub(r"<.*$", "", base)

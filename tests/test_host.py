@@ -280,3 +280,27 @@ def test_wide_weight_gradient_transposed_reads_are_bank_conflict_free():
     def plain(lane):
         return pixel(lane, 0) * 128 + (lane & 3) * 8
     assert _tr_b64_ways(plain) == 4
+
+
+def test_thin_weight_gradient_transposed_reads_are_bank_conflict_free():
+    # unet_amd/csrc/wgrad3.hip, wgrad_thin_kernel: 64-byte pixel rows, 32-byte granule b of column x stored in slot
+    # b ^ ((x >> 2) & 1); 32-byte rows are stored as they are
+    def pixel(lane, h):
+        lr, g = lane & 15, lane >> 4
+        return 16 * (g >> 1) + 8 * h + 4 * (g & 1) + (lr >> 2)
+    for rb, sw in ((64, lambda x: (x >> 2) & 1), (32, lambda x: 0)):
+        for h in range(2):
+            for blk in range(rb // 32):
+                def faddr(lane, h=h, blk=blk):
+                    v = pixel(lane, h)
+                    return v * rb + ((blk ^ sw(v & 15)) * 32) + (lane & 3) * 8
+                assert _tr_b64_ways(faddr) == 1
+                for dy in range(3):
+                    for dx in range(3):
+                        def saddr(lane, h=h, blk=blk, dy=dy, dx=dx):
+                            v = pixel(lane, h)
+                            r, c = v >> 4, v & 15
+                            return ((r + dy) * 18 + c + dx) * rb + ((blk ^ sw(c + dx)) * 32) + (lane & 3) * 8
+                        assert _tr_b64_ways(saddr) == 1, (rb, h, blk, dy, dx)
+    # 64-byte rows unpermuted: pixels four apart share their banks
+    assert _tr_b64_ways(lambda lane: pixel(lane, 0) * 64 + (lane & 3) * 8) == 2

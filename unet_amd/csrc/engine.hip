@@ -286,6 +286,7 @@ struct Builder {
         *partial_off = po; *pbias_off = pb; *nslab = slabs; *ntaps = p.ntaps_total;
         char kb[96];
         snprintf(kb, sizeof(kb), "wgrad_kernel<%s,%d,%d,%d,%d,%d>", u.dt ? "BF16" : "F32", p.ntaps_total / p.ntapg, ff, sf, wf, wsn);
+        wgrad_thick_label(u.dt, p, ff, sf, wf, wsn, kb, sizeof(kb));
         s.kernel = kb;
         double bpix = (double)p.bd[0] * p.bd[1] * p.bd[2] * u.nb;
         s.work = 2.0 * bpix * p.ntaps_total * (double)F * S; s.work_is_flops = 1;

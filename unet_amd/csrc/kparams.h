@@ -150,6 +150,7 @@ void conv2d_dma_label(int dtype, const IgemmParams& p, char* buf, size_t n);   /
 int launch_wgrad_dma(int dtype, const WgradParams& p, int ff, int sf, int wf, int wsn, hipStream_t st);   // 1: shape not served
 int launch_wgrad_thick(int dtype, const WgradParams& p, int ff, int sf, int wf, int wsn, hipStream_t st);   // wgrad3.hip; 1: shape not served
 bool wgrad_thick_config(int dtype, const WgradParams& p, int* ff, int* sf, int* wf, int* wsn);   // block shape wgrad3.hip wants for p
+void wgrad_thick_label(int dtype, const WgradParams& p, int ff, int sf, int wf, int wsn, char* buf, size_t n);   // its kernel's name, if it serves p
 int launch_reduce(const ReduceTable& tab, int total_blocks, hipStream_t st);   // total_blocks: sum of the descriptors' nblk
 int reduce_blocks_for(int total);
 int launch_pack(int dtype, const PackTable& tab, int total_blocks, hipStream_t st);

@@ -489,6 +489,207 @@ __global__ __launch_bounds__(256, 2) void wgrad_thick_s2_kernel(const WgradParam
     }
 }
 
+
+// ---- thin unit-stride layers: 32 x 32 channel blocks (FF = 2; 16 x 16 compiles, measured slower than wgrad2.hip) --------------------------------------------------------
+// These layers wait for memory: a tile's MFMA work is a fraction of the time its bytes take at a CU's share of the HBM
+// rate, so what matters is bytes in flight per CU and nothing else standing in the way.  Stages are half tiles as
+// above (10 or 20 KB), in a ring of R slots with R - 1 stages in flight and counted waits, two workgroups per CU.
+// The four waves split the TAPS (3 + 2 + 2 + 2), not the pixels: every wave reads all fixed-operand fragments of the
+// stage and the shifted fragments of its own taps, holds at most 3 x FF x FF accumulators, and writes its taps'
+// part of the slab itself - no combination pass through LDS at the end.  Rows are 32 FF bytes; 64-byte rows have
+// their two 32-byte granules swapped for columns with bit 2 set (pixels four apart otherwise share banks in a
+// transposed read of eight consecutive pixels), 32-byte rows need nothing.
+template <int FF, int R>
+__global__ __launch_bounds__(256, 2) void wgrad_thin_kernel(const WgradParams p) {
+    constexpr int RB = 32 * FF;                      // bytes per LDS row (16 FF bf16 channels), both operands
+    constexpr int PD = 18, SPX = 10 * PD;
+    constexpr int LPR = RB / 16, PPI = 64 / LPR;     // lanes per row, pixels per DMA wave-instruction
+    constexpr int NIF = 128 / PPI, NIS = (SPX + PPI - 1) / PPI;
+    constexpr int FBYTES = NIF * 1024, SBYTES = NIS * 1024, SLOT = FBYTES + SBYTES;
+    constexpr int NUF = NIF / 4, NUS = (NIS + 3) / 4;
+    constexpr int PT = NUF + NUS;                    // loads per wave and stage (waves past the end repeat an instruction)
+    constexpr int LA = R - 1;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, g = lane >> 4;
+    const int fb0 = blockIdx.y * 16 * FF, sb0 = blockIdx.z * 16 * FF;
+    const int H = p.bd[1], W = p.bd[2];
+    const int tap0 = wave == 0 ? 0 : 1 + 2 * wave, ntap = wave == 0 ? 3 : 2;   // taps 0-2, 3-4, 5-6, 7-8
+
+    v4f acc[3][FF][FF];
+    v4f accb[FF];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int a = 0; a < FF; ++a)
+#pragma unroll
+            for (int b = 0; b < FF; ++b) acc[t][a][b] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < FF; ++a) accb[a] = v4f{0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = wave == 3 && blockIdx.z == 0;
+
+    const int fpb = p.f0_pitch * 2, spb = p.s_pitch * 2;
+    const char* const fbase = p.f0 + (size_t)(p.f0_coff + fb0) * 2;
+    const char* const sbase = p.s + (size_t)(p.s_coff + sb0) * 2;
+    const char* const zero = reinterpret_cast<const char*>(g_zero_page_t) + (lane & 7) * 16;
+
+    // ---- per-lane DMA constants ------------------------------------------------------------------------------------
+    const int sl = lane % LPR;
+    auto src_chunk = [&](int x) { return FF == 2 ? ((((sl >> 1) ^ gswz64(x)) << 1) | (sl & 1)) : sl; };
+    int f_off[NUF], f_rc[NUF];
+#pragma unroll
+    for (int u = 0; u < NUF; ++u) {
+        const int ps = (wave + 4 * u) * PPI + lane / LPR;
+        const int r = ps >> 4, c = ps & 15;
+        f_off[u] = (r * W + c) * fpb + src_chunk(c) * 16;
+        f_rc[u] = (r << 8) | c;
+    }
+    int s_off[NUS], s_yx[NUS], s_dst[NUS];
+#pragma unroll
+    for (int u = 0; u < NUS; ++u) {
+        const int i = (wave + 4 * u) % NIS;
+        const int ps = i * PPI + lane / LPR;
+        s_dst[u] = FBYTES + i * 1024;
+        s_off[u] = 0; s_yx[u] = -1;
+        if (ps < SPX) {
+            const int py = ps / PD, px = ps - py * PD;
+            s_off[u] = (py * W + px) * spb + src_chunk(px) * 16;
+            s_yx[u] = (py << 8) | px;
+        }
+    }
+
+    const int tiles_per_img = p.ntile[1] * p.ntile[2];
+    auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)d) + 1u; };
+    auto fdiv = [](int n, unsigned mg) { return mg ? (int)__umulhi((unsigned)n, mg) : n; };
+    const unsigned mg_img = magic(tiles_per_img), mg_x = magic(p.ntile[2]);
+
+    // stage j of this workgroup: half (j & 1) of tile blockIdx.x + (j >> 1) * nsplit
+    auto issue_stage = [&](int j, int slot) {
+        const int tile = blockIdx.x + (j >> 1) * p.nsplit;
+        const int img = fdiv(tile, mg_img);
+        const int tr = tile - img * tiles_per_img;
+        const int tyi = fdiv(tr, mg_x);
+        const int txi = tr - tyi * p.ntile[2];
+        const int by0 = (tyi << 4) + 8 * (j & 1), bx0 = txi << 4;
+        char* dst = smem + slot * SLOT;
+        {
+            const char* fb = fbase + (((long long)img * H + by0) * W + bx0) * fpb;
+#pragma unroll
+            for (int u = 0; u < NUF; ++u) {
+                const bool ok = by0 + (f_rc[u] >> 8) < H && bx0 + (f_rc[u] & 255) < W;
+                dma16t(ok ? fb + f_off[u] : zero, dst + (wave + 4 * u) * 1024);
+            }
+        }
+        {
+            const int iy0 = by0 - 1, ix0 = bx0 - 1;
+            const char* sb = sbase + (((long long)img * H + iy0) * W + ix0) * spb;
+#pragma unroll
+            for (int u = 0; u < NUS; ++u) {
+                const bool ok = s_yx[u] >= 0 && (unsigned)(iy0 + (s_yx[u] >> 8)) < (unsigned)H && (unsigned)(ix0 + (s_yx[u] & 255)) < (unsigned)W;
+                dma16t(ok ? sb + s_off[u] : zero, dst + s_dst[u]);
+            }
+        }
+    };
+
+    // ---- per-lane fragment addresses: contraction slot 8 g + 4 h + q takes pixel v = 16 (g / 2) + 8 h + 4 (g % 2) + q -------
+    const int q = lr >> 2, pp = lr & 3;
+    int fa[2][FF], sa[2][3][FF];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int v = 16 * (g >> 1) + 8 * h + 4 * (g & 1) + q;
+        const int r = v >> 4, c = v & 15;
+#pragma unroll
+        for (int a = 0; a < FF; ++a) fa[h][a] = v * RB + (FF == 2 ? (a ^ gswz64(c)) * 32 : 0) + pp * 8;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int t = tap0 + (i < ntap ? i : 0);
+            const int dy = t / 3, dx = t - 3 * dy;
+#pragma unroll
+            for (int b = 0; b < FF; ++b)
+                sa[h][i][b] = ((r + dy) * PD + c + dx) * RB + (FF == 2 ? (b ^ gswz64(c + dx)) * 32 : 0) + pp * 8 + FBYTES;
+        }
+    }
+
+    const int ntw = p.tiles_total > (int)blockIdx.x ? (p.tiles_total - 1 - (int)blockIdx.x) / p.nsplit + 1 : 0;
+    const int nstage = 2 * ntw;
+    for (int j = 0; j < LA && j < nstage; ++j) issue_stage(j, j);
+    int slot = 0, slot_issue = LA % R;
+    for (int j = 0; j < nstage; ++j) {
+        const int ahead = min(LA - 1, nstage - 1 - j);
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PT) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                // stage j has landed everywhere, stage j - 1 has been consumed
+        asm volatile("" ::: "memory");
+        if (j + LA < nstage) issue_stage(j + LA, slot_issue);
+        slot_issue = slot_issue + 1 == R ? 0 : slot_issue + 1;
+        const char* sm = smem + slot * SLOT;
+        slot = slot + 1 == R ? 0 : slot + 1;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            uint4 afr[FF];
+#pragma unroll
+            for (int a = 0; a < FF; ++a) {
+                v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(sm + fa[0][a] + ks * 32 * RB));
+                v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(sm + fa[1][a] + ks * 32 * RB));
+                v8s f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                afr[a] = __builtin_bit_cast(uint4, f);
+            }
+            if (do_bias) {
+                const uint4 ones = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+#pragma unroll
+                for (int a = 0; a < FF; ++a)
+                    accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, afr[a]), __builtin_bit_cast(v8bf, ones), accb[a], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                if (i < ntap) {
+                    uint4 bfr[FF];
+#pragma unroll
+                    for (int b = 0; b < FF; ++b) {
+                        v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(sm + sa[0][i][b] + ks * 2 * PD * RB));
+                        v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(sm + sa[1][i][b] + ks * 2 * PD * RB));
+                        v8s f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        bfr[b] = __builtin_bit_cast(uint4, f);
+                    }
+#pragma unroll
+                    for (int a = 0; a < FF; ++a)
+#pragma unroll
+                        for (int b = 0; b < FF; ++b)
+                            acc[i][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, afr[a]), __builtin_bit_cast(v8bf, bfr[b]), acc[i][a][b], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- every wave writes its taps of the workgroup's slab ----------------------------------------------------------
+    const size_t slab = (size_t)blockIdx.x;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (i < ntap) {
+            const size_t tbase = (slab * p.ntaps_total + tap0 + i) * p.F;
+#pragma unroll
+            for (int a = 0; a < FF; ++a)
+#pragma unroll
+                for (int b = 0; b < FF; ++b)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int f = fb0 + a * 16 + 4 * g + j;
+                        const int sx = sb0 + b * 16 + lr;
+                        p.partial[(tbase + f) * p.S + sx] = acc[i][a][b][j];
+                    }
+        }
+    }
+    if (do_bias && lr == 0) {
+#pragma unroll
+        for (int a = 0; a < FF; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) p.partial_bias[slab * p.F + fb0 + a * 16 + 4 * g + j] = accb[a][j];
+    }
+}
+
 }  // namespace
 
 // Which kernel of this file serves `p`: 0 none, 1 unit stride (64 x 64 blocks), 2 / 3 gather stride 2 with 64 x 32 /
@@ -530,8 +731,54 @@ bool wgrad_thick_config(int dtype, const WgradParams& p, int* ff, int* sf, int* 
     return true;
 }
 
+// Thin unit-stride layers: block shape (2,2,1,1) of the general policy.
+static bool thin_serves(int dtype, const WgradParams& p, int ff, int sf, int wf, int wsn) {
+    static const bool on = getenv("MI_NO_WGRAD_THIN") == nullptr && getenv("MI_NO_WGRAD_THICK") == nullptr &&
+                           !(getenv("MI_NO_WGRAD_DMA") && atoi(getenv("MI_NO_WGRAD_DMA")) != 0);
+    // 16 x 16 blocks stay with the whole-tile ring of wgrad2.hip: a 10 KB half-tile stage is too little work per barrier
+    if (!on || !dtype || wf != 1 || wsn != 1 || ff != 2 || sf != 2) return false;
+    if (p.ntaps_total != 9 || p.ntapg != 1 || p.ss != 1) return false;
+    if (p.bd[0] != 1 || p.tlog[0] != 0 || p.tlog[1] != 4 || p.tlog[2] != 4 || p.omin[1] != -1 || p.omin[2] != -1) return false;
+    if (p.pd[1] != 18 || p.pd[2] != 18 || p.F % (16 * ff) || p.S % (16 * ff) || p.f0_c < p.F) return false;
+    for (int t = 0; t < 9; ++t)
+        if (p.tap_off[t] != (t / 3) * 18 + t % 3) return false;
+    if (p.sd[1] != p.bd[1] || p.sd[2] != p.bd[2] || p.bd[1] > 255 * 16 || p.bd[2] > 255 * 16) return false;
+    if ((long long)p.bd[1] * p.bd[2] * (p.s_pitch > p.f0_pitch ? p.s_pitch : p.f0_pitch) * 2 >= (1ll << 30)) return false;
+    return true;
+}
+
+// step-table name of the kernel of this file that serves p under block shape (ff, sf, wf, wsn); buf is left alone when none does
+void wgrad_thick_label(int dtype, const WgradParams& p, int ff, int sf, int wf, int wsn, char* buf, size_t n) {
+    if (thin_serves(dtype, p, ff, sf, wf, wsn)) { snprintf(buf, n, "wgrad_thin_kernel<2>"); return; }
+    const int k = thick_kind(dtype, p);
+    if (k == 1) snprintf(buf, n, "wgrad_thick_kernel");
+    else if (k) snprintf(buf, n, "wgrad_thick_s2_kernel<%d>", k == 3 ? 1 : 2);
+}
+
+// 0 launched, 1 not served
+static int launch_wgrad_thin(int dtype, const WgradParams& p, int ff, int sf, int wf, int wsn, hipStream_t st) {
+    if (!thin_serves(dtype, p, ff, sf, wf, wsn)) return 1;
+    const dim3 grid(p.nsplit, p.F / (16 * ff), p.S / (16 * ff));
+    constexpr int R = 3;
+    const size_t lds = (size_t)R * (8 + 12) * 1024;
+    static bool done = false;
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_thin_kernel<2, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { mi_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return -2; }
+        done = true;
+    }
+    hipLaunchKernelGGL((wgrad_thin_kernel<2, R>), grid, dim3(256), lds, st, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { mi_set_error(std::string("wgrad_thin launch: ") + hipGetErrorString(e)); return -2; }
+    return 0;
+}
+
 // Returns 0 when launched, 1 when this file does not serve the shape (the caller falls back), < 0 on error.
 int launch_wgrad_thick(int dtype, const WgradParams& p, int ff, int sf, int wf, int wsn, hipStream_t st) {
+    {
+        const int r = launch_wgrad_thin(dtype, p, ff, sf, wf, wsn, st);
+        if (r <= 0) return r;
+    }
     int cf, cs, cwf, cws;
     if (!wgrad_thick_config(dtype, p, &cf, &cs, &cwf, &cws)) return 1;
     if (cf != ff || cs != sf || cwf != wf || cws != wsn) { mi_set_error("wgrad_thick: block shape differs from the one the slabs were sized for"); return -2; }
