@@ -304,3 +304,44 @@ def test_thin_weight_gradient_transposed_reads_are_bank_conflict_free():
                         assert _tr_b64_ways(saddr) == 1, (rb, h, blk, dy, dx)
     # 64-byte rows unpermuted: pixels four apart share their banks
     assert _tr_b64_ways(lambda lane: pixel(lane, 0) * 64 + (lane & 3) * 8) == 2
+
+
+@pytest.mark.parametrize("shape", [(3, 32, 32), (2, 40, 56), (1, 16, 16), (1, 130, 258), (2, 34, 30)])
+@pytest.mark.parametrize("rows_groups", [(2, 16), (4, 8)])
+def test_strip_convolution_addresses_stay_inside_the_tensors(shape, rows_groups):
+    # unet_amd/csrc/small.hip, c1_s2_fwd32_kernel: its loads are unconditional (clamped row, clamped left neighbour,
+    # column 0 for lanes past the last column), so every index it forms must lie inside the image; every output pixel
+    # is stored exactly once
+    nb, H, W = shape
+    ROWS, NG = rows_groups
+    cd1, cd2 = (H + 1) // 2, (W + 1) // 2
+    assert W >= 2 * cd2                         # the launcher's condition for this kernel
+    lo, hi, stores = 10 ** 9, -1, set()
+    for img in range(nb):
+        for by in range((cd1 + ROWS * NG - 1) // (ROWS * NG)):
+            for bx in range((cd2 + 63) // 64):
+                for pl in range(64):
+                    cx = bx * 64 + pl
+                    ok = cx < cd2
+                    cxs = cx if ok else 0
+                    xl = 0 if cxs == 0 else -1
+                    cyb = by * ROWS * NG
+                    fys = [2 * cyb - 1 + j for j in range(2 * ROWS + 1)]
+                    for gi in range(NG):
+                        cy0 = cyb + gi * ROWS
+                        if cy0 >= cd1:
+                            break
+                        if gi + 1 < NG:
+                            fys += [2 * cy0 + 2 * ROWS + j for j in range(2 * ROWS)]
+                        for r in range(ROWS):
+                            if ok and cy0 + r < cd1:
+                                gp = img * cd1 * cd2 + (cy0 + r) * cd2 + cx
+                                assert gp not in stores
+                                stores.add(gp)
+                    for fy in fys:
+                        fyc = min(max(fy, 0), H - 1)
+                        for d in (xl, 0, 1):
+                            idx = img * H * W + fyc * W + 2 * cxs + d
+                            lo, hi = min(lo, idx), max(hi, idx)
+    assert lo >= 0 and hi < nb * H * W
+    assert len(stores) == nb * cd1 * cd2

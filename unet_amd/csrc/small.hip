@@ -168,6 +168,144 @@ __global__ __launch_bounds__(256) void c1_s2_fwd_kernel(const C1Params p) {
     }
 }
 
+// ---- the same for 2-D and N = 32 (the first encoder layer with its residual branch, the data gradient of the last
+// transposed convolution), as a strip walk.  Measured on the kernel above with its parts switched off: without the
+// stores, the FMAs and the statistics it still takes 34 of its 58 us - the per-workgroup set-up (weights to LDS, bias,
+// statistics epilogue with 64 fp64 atomics) and 27 branch-guarded gather loads in front of 4 rows of work.  Here a
+// workgroup owns 64 columns x NG groups of ROWS coarse rows: set-up and epilogue once per strip, the input rows of
+// group g + 1 are requested before group g is multiplied (consecutive groups share one input row: 2 ROWS new rows
+// each), and the loads are unconditional (only fine row -1 and fine column -1 fall outside: the address is clamped and
+// the value replaced by zero).
+template <class TR, int ROWS, int NG>
+__global__ __launch_bounds__(256) void c1_s2_fwd32_kernel(const C1Params p) {
+    constexpr int ESZ = TR::ESZ;
+    constexpr int N = 32, NR = 2 * ROWS + 1;
+    __shared__ __attribute__((aligned(16))) float wl[9 * N];
+    __shared__ float sst[2 * 16 * N];
+    const int grp = threadIdx.x & 3, pl = threadIdx.x >> 2;
+    const int img = blockIdx.z;
+    const int cx = blockIdx.x * 64 + pl;
+    const bool lane_ok = cx < p.cd[2];
+    const int H = p.fd[1], W = p.fd[2];
+    const size_t cpix = (size_t)p.cd[1] * p.cd[2];
+    const int cxs = lane_ok ? cx : 0;              // lanes past the last column read column 0 and store nothing
+    const bool left = cxs == 0;
+    const float* const xc = p.x1 + (size_t)img * H * W + 2 * cxs;   // fine column 2 cx of row 0
+    // the loads carry no condition (clamped row, clamped left neighbour), the zeroing happens where the values are
+    // first used: a guarded load is waited for on the spot, which would undo the prefetch
+    const int xl = left ? 0 : -1;
+    auto load_raw = [&](int fy, float* v) {
+        const int fyc = min(max(fy, 0), H - 1);
+        const float* r = xc + (size_t)fyc * W;
+        v[0] = r[xl]; v[1] = r[0]; v[2] = r[1];
+    };
+    auto mask_row = [&](int fy, float* v) {
+        const bool rok = (unsigned)fy < (unsigned)H;
+        v[0] = (rok && !left) ? v[0] : 0.f; v[1] = rok ? v[1] : 0.f; v[2] = rok ? v[2] : 0.f;
+    };
+    const int cy_begin = blockIdx.y * ROWS * NG;
+    float xr[NR][3], xn[2 * ROWS][3];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) load_raw(2 * cy_begin - 1 + j, xr[j]);
+    for (int i = threadIdx.x; i < N * 9; i += 256) {
+        const int n = i / 9, k = i - n * 9;
+        wl[k * N + n] = (n < p.n_w1) ? p.w[n * 9 + k] : p.w2[(n - p.n_w1) * 9 + k];
+    }
+    float bv[8], s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ch = grp * 8 + e;
+        bv[e] = (p.bias && ch >= p.bias_c0) ? p.bias[ch - p.bias_c0] : 0.f;
+        s1[e] = 0.f; s2[e] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < NR; ++j) mask_row(2 * cy_begin - 1 + j, xr[j]);
+    __syncthreads();
+    char* const dst0 = (p.y2_out && grp * 8 >= p.n_o1) ? p.y2_out + ((size_t)p.y2o_coff + grp * 8 - p.n_o1) * ESZ : p.y_out + ((size_t)p.y_coff + grp * 8) * ESZ;
+    const int dpitch = ((p.y2_out && grp * 8 >= p.n_o1) ? p.y2o_pitch : p.y_pitch) * ESZ;
+#pragma unroll 1
+    for (int gi = 0; gi < NG; ++gi) {
+        const int cy0 = cy_begin + gi * ROWS;
+        if (cy0 >= p.cd[1]) break;
+        asm volatile("" ::: "memory");   // the weights are read from LDS tap by tap in every group: 72 registers hoisted out of the loop cost more
+        if (gi + 1 < NG) {
+#pragma unroll
+            for (int j = 0; j < 2 * ROWS; ++j) load_raw(2 * cy0 + 2 * ROWS + j, xn[j]);
+        }
+        float acc[ROWS][8];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[r][e] = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float4 a = *reinterpret_cast<const float4*>(wl + (ky * 3 + kx) * N + grp * 8);
+                const float4 b = *reinterpret_cast<const float4*>(wl + (ky * 3 + kx) * N + grp * 8 + 4);
+                const float w8[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+                    const float xv = xr[2 * r + ky][kx];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[r][e] += xv * w8[e];
+                }
+                if (kx == 2) __builtin_amdgcn_sched_barrier(0);   // one kernel row of weights in registers at a time
+            }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int cy = cy0 + r;
+            if (lane_ok && cy < p.cd[1]) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    o[e] = acc[r][e] + bv[e];
+                    s1[e] += acc[r][e];
+                    s2[e] += acc[r][e] * acc[r][e];
+                }
+                const size_t gp = (size_t)img * cpix + (size_t)cy * p.cd[2] + cx;
+                store_n<TR, 8>(dst0 + gp * dpitch, o);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) xr[0][k] = xr[2 * ROWS][k];
+#pragma unroll
+        for (int j = 0; j < 2 * ROWS; ++j) {
+            mask_row(2 * cy0 + 2 * ROWS + j, xn[j]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) xr[1 + j][k] = xn[j][k];
+        }
+    }
+    if (p.stats) {
+        // four channel groups per column: a 16-lane row holds four columns, two DPP row shifts add them up in lanes
+        // 12..15; the 16 rows of the workgroup then meet in LDS ([2][16 rows][N]), fixed order, then fp64 accumulators
+        const int slot = (blockIdx.x + blockIdx.y) % MI_NSLOT;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            s1[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1[e]), 0x114, 0xf, 0xf, true));
+            s1[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1[e]), 0x118, 0xf, 0xf, true));
+            s2[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s2[e]), 0x114, 0xf, 0xf, true));
+            s2[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s2[e]), 0x118, 0xf, 0xf, true));
+        }
+        const int row = threadIdx.x >> 4;
+        if ((threadIdx.x & 15) >= 12) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                sst[row * N + grp * 8 + e] = s1[e];
+                sst[(16 + row) * N + grp * 8 + e] = s2[e];
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < p.nstat * 2; i += 256) {
+            const int ch = i >> 1, k = i & 1;
+            float a = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a += sst[(k * 16 + r) * N + ch];
+            atomicAdd(&p.stats[(((size_t)img * MI_NSLOT + slot) * p.stats_c) * 2 + i], (double)a);
+        }
+    }
+}
+
 // ---- N -> 1 stride-2 transposed convolution (k=3, pad=1, output_padding=1) ---------------
 // Phase 1: every thread forms the KK tap products d[k] = <Y[c][:], w[:][k]> of one coarse pixel of the
 // workgroup's patch and parks them in LDS.  Phase 2: every fine pixel sums the 1, 2, 4 (or 8) products that
@@ -735,6 +873,15 @@ int run_c1_fwd(const C1Params& p, hipStream_t st) {
     constexpr int KK = KZ * 9, ROWS = 4;
     const int ppb = 256 / (p.N / 8);
     const size_t lds = (size_t)(p.N * KK + 2 * ppb * p.N) * sizeof(float);
+    if (KZ == 1 && p.N == 32 && (size_t)p.fd[1] * p.fd[2] < (1u << 30) && p.fd[2] >= 2 * p.cd[2] && p.fd[1] >= 1) {
+        static const bool strip = getenv("MI_NO_C1_STRIP") == nullptr;
+        if (strip) {
+            constexpr int R2 = 4, G2 = 8;      // 32 coarse rows per workgroup
+            dim3 grid((p.cd[2] + 63) / 64, (p.cd[1] + R2 * G2 - 1) / (R2 * G2), p.nb);
+            hipLaunchKernelGGL((c1_s2_fwd32_kernel<TR, R2, G2>), grid, dim3(256), 0, st, p);
+            return check_launch("c1_s2_fwd32");
+        }
+    }
     if (int rc = small_lds(c1_s2_fwd_kernel<TR, KZ>, lds)) return rc;
     dim3 grid((p.cd[2] + ppb - 1) / ppb, (p.cd[1] + ROWS * C1F_YG - 1) / (ROWS * C1F_YG), p.nb * p.cd[0]);
     hipLaunchKernelGGL((c1_s2_fwd_kernel<TR, KZ>), grid, dim3(256), lds, st, p);
