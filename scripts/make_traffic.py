@@ -22,6 +22,8 @@ def label(name: str) -> str:
             return "norm1_bwd_kernels"
         return base
     kern, tr, rest = m.group(1), m.group(2), [a.strip() for a in m.group(3).split(",") if a.strip()]
+    if kern == "c1_s2_fwd32_kernel":         # the strip form runs under the step label of the kernel it stands in for
+        return f"c1_s2_fwd_kernel<{tr}>"
     if kern in ("norm_bwd_reduce_kernel", "norm_bwd_apply_kernel"):
         return f"norm_bwd_kernels<{tr}>"
     if kern in ("igemm_kernel", "igemm2d_kernel"):
