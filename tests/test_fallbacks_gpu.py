@@ -1,0 +1,51 @@
+"""The kernel families added on top of the register-staged kernels can be switched off one by one (environment
+variables read once per process): the older kernels then serve those layers.  Each switch is run in a child process on
+one bf16 training step (forward, loss, backward; 16-128 channels, 96 x 160, dropout 0.1 with a fixed seed) and compared
+with the default selection: same arithmetic in a different summation order.  Most pairs agree bit for bit or to 1e-8;
+the first-layer pair differs by 1e-7 in its norm statistics (fp32 partial sums taken over other pixel groups; 7e-7 on
+the logits in fp32 mode), which bf16 storage and the PReLU kinks of twenty layers turn into 4e-3 on the logits and up to
+7 % on single weight-gradient tensors (scripts/fallback_noise.py prints the figures).  The bounds below are set for
+that: they still catch a kernel that computes something else."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+SWITCHES = ["MI_NO_CONV_DMA", "MI_NO_CONV_PHASE", "MI_NO_CONV_S2", "MI_NO_CONV_K16", "MI_NO_WGRAD_DMA", "MI_NO_WGRAD_THICK",
+            "MI_NO_WGRAD_THICK_S2", "MI_NO_WGRAD_THIN", "MI_NO_C1_STRIP", "MI_NO_SIDE_STREAM"]
+
+
+def run_child(tmp_path, switch):
+    out = str(tmp_path / ((switch or "default") + ".pt"))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("MI_NO_")}
+    if switch:
+        env[switch] = "1"
+    r = subprocess.run([sys.executable, os.path.join(HERE, "fallback_child.py"), out], env=env, capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return torch.load(out, weights_only=True)
+
+
+@pytest.fixture(scope="module")
+def baseline(tmp_path_factory, dev):
+    return run_child(tmp_path_factory.mktemp("fallbacks"), None)
+
+
+@pytest.mark.parametrize("switch", SWITCHES)
+def test_older_kernels_agree_with_the_default_selection(tmp_path, baseline, switch):
+    got = run_child(tmp_path, switch)
+    assert rel_l2(got["logits"], baseline["logits"]) < 2e-2
+    assert abs(got["loss"] - baseline["loss"]) < 2e-3 * abs(baseline["loss"])
+    # Two kinds of gradient are round-off of either kernel and cannot be compared relatively: a conv bias in front of an
+    # instance norm (analytically zero) and a PReLU slope (one scalar, a sum of terms of both signs over a whole
+    # tensor).  A tensor passes on a relative bound or on an absolute one at the scale of the largest gradient.
+    scale = max(float(g.abs().max()) for g in baseline["grads"].values())
+    for k, g in baseline["grads"].items():
+        d = got["grads"][k]
+        ok = rel_l2(d, g) < 0.15 or float((d - g).abs().max()) < 5e-3 * scale
+        assert ok, (k, rel_l2(d, g), float((d - g).abs().max()), scale)
