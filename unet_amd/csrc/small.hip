@@ -359,37 +359,55 @@ __global__ __launch_bounds__(256) void c1_s2_T_kernel(const C1Params p) {
         // on the matrix cores: A = weights (16 tap rows x 32 channels from LDS, bf16, rows >= KK zero), B = the
         // pixel's channels straight from memory (lane (pixel, g) holds channels 8g..8g+7 of a 32-channel chunk)
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, g = lane >> 4;
+        // the four 16-pixel groups of the wave are loaded together and without a condition (a pixel outside the tensor
+        // reads pixel 0 of the image and is zeroed afterwards): a load under a condition is waited for where it stands,
+        // which made four dependent round trips out of one
+        size_t gpx[4];
+        bool okp[4];
 #pragma unroll
         for (int mf = 0; mf < 4; ++mf) {
             const int pl = wave * 64 + mf * 16 + lr;                // pixel of the patch this lane feeds
             const int qx = pl % PX, qy = (pl / PX) % PY, qz = pl / (PX * PY);
             const int pz = cz0 + qz, py = cy0 + qy, px = cx0 + qx;
-            const bool ok = pz < p.cd[0] && py < p.cd[1] && px < p.cd[2];
-            const size_t gp = (size_t)img * cpix + ((size_t)pz * p.cd[1] + py) * p.cd[2] + px;
-            v4f acc[TB];
+            okp[mf] = pz < p.cd[0] && py < p.cd[1] && px < p.cd[2];
+            gpx[mf] = (size_t)img * cpix + (okp[mf] ? ((size_t)pz * p.cd[1] + py) * p.cd[2] + px : 0);
+        }
+        v4f acc[4][TB];
 #pragma unroll
-            for (int tb = 0; tb < TB; ++tb) acc[tb] = v4f{0.f, 0.f, 0.f, 0.f};
-            for (int n0 = 0; n0 < N; n0 += 32) {
-                const int ch = n0 + 8 * g;
-                uint4 b = make_uint4(0u, 0u, 0u, 0u);
-                if (ok && ch < N) {
-                    const char* src = (p.y2 && ch >= p.n_y1) ? p.y2 + (gp * p.y2_pitch + p.y2_coff + ch - p.n_y1) * ESZ
-                                                              : p.y + (gp * p.y_pitch + p.y_coff + ch) * ESZ;
-                    b = *reinterpret_cast<const uint4*>(src);
-                }
+        for (int mf = 0; mf < 4; ++mf)
 #pragma unroll
-                for (int tb = 0; tb < TB; ++tb) {
-                    const uint4 a = *reinterpret_cast<const uint4*>(wb + (size_t)(tb * 16 + lr) * NC + ch);
-                    acc[tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b), acc[tb], 0, 0, 0);
-                }
+            for (int tb = 0; tb < TB; ++tb) acc[mf][tb] = v4f{0.f, 0.f, 0.f, 0.f};
+        for (int n0 = 0; n0 < N; n0 += 32) {
+            const int ch = n0 + 8 * g;
+            const bool chok = ch < N;
+            const int chs = chok ? ch : 0;
+            const bool second = p.y2 && chs >= p.n_y1;
+            const char* const sbase = second ? p.y2 + (size_t)(p.y2_coff + chs - p.n_y1) * ESZ : p.y + (size_t)(p.y_coff + chs) * ESZ;
+            const size_t spitch = (size_t)(second ? p.y2_pitch : p.y_pitch) * ESZ;
+            uint4 b[4];
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf) b[mf] = *reinterpret_cast<const uint4*>(sbase + gpx[mf] * spitch);
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf)
+                if (!(okp[mf] && chok)) b[mf] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int tb = 0; tb < TB; ++tb) {
+                const uint4 a = *reinterpret_cast<const uint4*>(wb + (size_t)(tb * 16 + lr) * NC + chs);
+#pragma unroll
+                for (int mf = 0; mf < 4; ++mf)
+                    acc[mf][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b[mf]), acc[mf][tb], 0, 0, 0);
             }
-            // lane (pixel lr, g) holds taps 4g..4g+3 of each 16-tap block
+        }
+        // lane (pixel lr, g) holds taps 4g..4g+3 of each 16-tap block
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) {
+            const int pl = wave * 64 + mf * 16 + lr;
 #pragma unroll
             for (int tb = 0; tb < TB; ++tb)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int k = tb * 16 + 4 * g + j;
-                    if (k < KK) D[k * NP + pl] = acc[tb][j];
+                    if (k < KK) D[k * NP + pl] = acc[mf][tb][j];
                 }
         }
     } else {
