@@ -38,6 +38,8 @@ CASES = [
     (2, (18, 30), 32, 64, 3, 2, False),      # odd output extents: ragged tiles of the stride-2 gather / scatter kernels
     (2, (36, 20), 64, 128, 3, 2, False),     # two contraction chunks with resident weights
     (2, (10, 14), 64, 32, 3, 2, True),
+    (2, (20, 36), 128, 64, 3, 2, False),     # wide contraction: the stride-2 gather streams its tap tiles with the patches
+    (2, (10, 14), 192, 128, 3, 2, True),     # the same in the data gradient of a transposed convolution (two sources' worth of channels)
     (2, (40, 24), 64, 64, 3, 1, False),      # several tiles per workgroup, last tile row ragged
     (2, (24, 40), 16, 32, 3, 1, False),      # 16 contraction channels: two taps per MFMA step (bf16)
     (2, (20, 20), 16, 64, 3, 1, False),

@@ -598,8 +598,16 @@ int launch_conv2d_phase_t(const IgemmParams& pin, hipStream_t st) {
 // components of the input: component (ry, rx) = pixels (2i - ry, 2j - rx), and inside a component the gather has unit
 // stride, so the fragment reads look like those of the unit-stride kernel.  One stage = one (tile, chunk, component):
 // a 17 x 17 component patch with 1, 2, 2 or 4 taps (ky = 1 lives in ry = 0 at row offset 0; ky = 0 and 2 in ry = 1 at
-// row offsets 0 and 1; the same along x).  Patches are double-buffered, the weights of all chunks stay in LDS.
-template <class TR, int NFRAG>
+// row offsets 0 and 1; the same along x).  Patches are double-buffered.  WRES: the weights of all chunks stay in LDS;
+// otherwise (wide contractions, 64 output channels per workgroup) a stage's 1, 2, 2 or 4 tap tiles travel with its
+// patch into the stage's half of a double buffer: one 4 KiB tap tile = four DMA wave-instructions, one per wave.
+__host__ __device__ constexpr int s2_ntap(int c) { return c == 0 ? 1 : c == 3 ? 4 : 2; }
+__host__ __device__ constexpr int s2_tap(int c, int i) {     // i-th tap of component c = (ry, rx), in (iy, ix) order
+    const int ry = c >> 1, rx = c & 1;
+    const int iy = rx ? i >> 1 : i, ix = rx ? i & 1 : 0;
+    return (ry ? 2 * iy : 1) * 3 + (rx ? 2 * ix : 1);
+}
+template <class TR, int NFRAG, bool WRES>
 __global__ __launch_bounds__(256, 2) void conv2d_s2_kernel(const IgemmParams p) {
     constexpr int ESZ = TR::ESZ;
     constexpr int KCE = 64 / ESZ;
@@ -614,8 +622,10 @@ __global__ __launch_bounds__(256, 2) void conv2d_s2_kernel(const IgemmParams p) 
     constexpr int NUW = (NIW + 3) / 4;
     constexpr int WBYTES = WROWS * 64;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
+    static_assert(WRES || NFRAG == 4, "streamed weights: one DMA instruction per wave and tap tile");
+    constexpr int WSTAGE = 4 * NT * 64;            // streamed weights: room for the four tap tiles of component (1, 1)
     char* const smP = smem;
-    char* const smW = smem + 2 * PBYTES;           // [chunk][tap][n] rows
+    char* const smW = smem + 2 * PBYTES;           // WRES: [chunk][tap][n] rows; else two stage buffers of [tap of the stage][n] rows
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -627,6 +637,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_s2_kernel(const IgemmParams p) 
     const int slot = blockIdx.x % MI_NSLOT;
     const int nkc = p.K / KCE;
     const int nstage = p.tpw * nkc * 4;
+    // streamed weights: this wave moves rows 16 wave .. 16 wave + 15 of every tap tile
+    const int ws_off = WRES ? 0 : ((n0 + chan_of_row_v<NFRAG>(wave, lane >> 2)) * p.K) * ESZ + ((lane & 3) ^ swz(lane >> 2)) * 16;
+    const int tap_bytes = p.N * p.K * ESZ;
     const int spb0 = p.in0_pitch * ESZ, spb1 = p.in1_pitch * ESZ;
     const int nkc0 = min(nkc, p.in0_c / KCE);
 
@@ -668,6 +681,21 @@ __global__ __launch_bounds__(256, 2) void conv2d_s2_kernel(const IgemmParams p) 
                 const bool ok = d_yx[u] >= 0 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
                 dma16(ok ? pb + off : zero, dst + i * 1024);
             }
+            if (!WRES) {
+                const char* wb = p.w + (size_t)q_kc * KCE * ESZ + ws_off;
+                char* wd = smW + (q_stage & 1) * WSTAGE + wave * 1024;
+                // tap tiles of component q_c in fragment order; the counts 1, 2, 2, 4 are wave-uniform
+                if (q_c == 0) {
+                    dma16(wb + (size_t)s2_tap(0, 0) * tap_bytes, wd);
+                } else if (q_c == 1) {
+                    dma16(wb + (size_t)s2_tap(1, 0) * tap_bytes, wd); dma16(wb + (size_t)s2_tap(1, 1) * tap_bytes, wd + NT * 64);
+                } else if (q_c == 2) {
+                    dma16(wb + (size_t)s2_tap(2, 0) * tap_bytes, wd); dma16(wb + (size_t)s2_tap(2, 1) * tap_bytes, wd + NT * 64);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dma16(wb + (size_t)s2_tap(3, i) * tap_bytes, wd + i * NT * 64);
+                }
+            }
         }
         ++q_stage;
         if (++q_c == 4) {
@@ -677,7 +705,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_s2_kernel(const IgemmParams p) 
     };
 
     // resident weights: every chunk's [tap][n] rows
-    for (int c = 0; c < nkc; ++c) {
+    for (int c = 0; WRES && c < nkc; ++c) {
 #pragma unroll
         for (int u = 0; u < NUW; ++u) {
             const int i = (wave + 4 * u) % NIW;
@@ -713,10 +741,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_s2_kernel(const IgemmParams p) 
 #pragma unroll
                 for (int nf = 0; nf < NFRAG; ++nf) acc[mf][nf] = v4f{0.f, 0.f, 0.f, 0.f};
         }
-        const char* wbuf = smW + kc * WBYTES;
+        const char* wres = smW + kc * WBYTES;
 #pragma unroll
         for (int c = 0; c < 4; ++c, ++stage) {
             const int ry = c >> 1, rx = c & 1;
+            const char* wbuf = WRES ? wres : smW + (stage & 1) * WSTAGE;
             const int nrow = 4 + ry, ncol = 1 + rx;
             const int poff = (stage & 1) * PBYTES;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -735,7 +764,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_s2_kernel(const IgemmParams p) 
                 for (int ix = 0; ix <= rx; ++ix) {
                     // ry = 0: ky = 1 at row offset 0; ry = 1: ky = 0 at offset 0, ky = 2 at offset 1 (x alike)
                     const int ky = ry ? 2 * iy : 1, kx = rx ? 2 * ix : 1;
-                    const int t = ky * 3 + kx;
+                    const int t = WRES ? ky * 3 + kx : (rx ? 2 * iy + ix : iy);     // streamed: position inside the stage's tiles
                     uint4 afr[NFRAG];
 #pragma unroll
                     for (int nf = 0; nf < NFRAG; ++nf) afr[nf] = *reinterpret_cast<const uint4*>(wbuf + (t * NT + nf * 16) * 64 + w_lane);
@@ -756,15 +785,15 @@ __global__ __launch_bounds__(256, 2) void conv2d_s2_kernel(const IgemmParams p) 
     if (do_stats) flush_stats<NFRAG>(p, smem, s1, s2, wave, lr, g, n0, img_wg, slot);
 }
 
-template <class TR, int NFRAG>
+template <class TR, int NFRAG, bool WRES>
 int launch_conv2d_s2_t(const IgemmParams& pin, hipStream_t st) {
     IgemmParams p = pin;
     if (!p.out1) p.out0_c = p.N;
     constexpr int NT = NFRAG * 16;
     const int nkc = p.K / (64 / TR::ESZ);
-    const size_t lds = (size_t)2 * 19 * 1024 + (size_t)nkc * 9 * NT * 64;
+    const size_t lds = (size_t)2 * 19 * 1024 + (WRES ? (size_t)nkc * 9 * NT * 64 : (size_t)2 * 4 * NT * 64);
     p.tpw = tiles_per_wg(p, NT);
-    auto kern = conv2d_s2_kernel<TR, NFRAG>;
+    auto kern = conv2d_s2_kernel<TR, NFRAG, WRES>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { mi_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return -2; }
@@ -1138,6 +1167,12 @@ static int s2_nfrag(int dtype, const IgemmParams& p) {
         if (p.N % (nf * 16) == 0 && (size_t)nkc * 9 * nf * 16 * 64 <= 40 * 1024) return nf;
     return 0;
 }
+// stride-2 gather with streamed weights: 64 output channels per workgroup where the resident form would have to
+// take fewer (every channel block stages the same patches again)
+static bool s2_streamed(int dtype, const IgemmParams& p) {
+    static const bool off = getenv("MI_NO_CONV_S2_STREAM") != nullptr;
+    return !off && p.N % 64 == 0 && s2_nfrag(dtype, p) < 4;
+}
 static int conv2d_dma_kind(int dtype, const IgemmParams& p) {
     const int kce = 64 / (dtype ? 2 : 4);
     if (p.id[0] != 1 || p.tlog[0] != 0 || p.tlog[1] != 4 || p.tlog[2] != 4 || p.pd[0] != 1) return 0;
@@ -1163,7 +1198,7 @@ static int conv2d_dma_kind(int dtype, const IgemmParams& p) {
         if (p.omin[1] != -1 || p.omin[2] != -1) return 0;
         for (int t = 0; t < 9; ++t)
             if (p.tap_off[t] != (t / 3) * 33 + t % 3) return 0;
-        if (s2_nfrag(dtype, p) == 0) return 0;
+        if (s2_nfrag(dtype, p) == 0 && !s2_streamed(dtype, p)) return 0;
         return 3;
     }
     if (p.sa != 1) return 0;
@@ -1202,6 +1237,7 @@ void conv2d_dma_label(int dtype, const IgemmParams& p, char* buf, size_t n) {
     const int kind = conv2d_dma_kind(dtype, p);
     if (kind == 5) snprintf(buf, n, "conv2d_s2k16_kernel<%d>", (p.N % 64 == 0) ? 4 : (p.N % 32 == 0) ? 2 : 1);
     else if (kind == 4) snprintf(buf, n, "conv2d_k16_kernel<%d>", (p.N % 64 == 0) ? 4 : (p.N % 32 == 0) ? 2 : 1);
+    else if (kind == 3 && s2_streamed(dtype, p)) snprintf(buf, n, "conv2d_s2_kernel<%s,4,streamed>", tr);
     else if (kind == 3) snprintf(buf, n, "conv2d_s2_kernel<%s,%d>", tr, s2_nfrag(dtype, p));
     else if (kind == 2) snprintf(buf, n, "conv2d_phase_kernel<%s,%d>", tr, (p.N % 32 == 0) ? 2 : 1);
     else snprintf(buf, n, "conv2d_dma_kernel<%s,%d>", tr, (p.N % 64 == 0) ? 4 : (p.N % 32 == 0) ? 2 : 1);
@@ -1220,7 +1256,8 @@ int launch_conv2d_dma(int dtype, const IgemmParams& p, hipStream_t st) {
     }
     if (conv2d_dma_kind(dtype, p) == 3) {
         const int nfs = s2_nfrag(dtype, p);
-#define S2_CASE(TRT) do { if (nfs == 4) return launch_conv2d_s2_t<TRT, 4>(p, st); if (nfs == 2) return launch_conv2d_s2_t<TRT, 2>(p, st); return launch_conv2d_s2_t<TRT, 1>(p, st); } while (0)
+        if (s2_streamed(dtype, p)) return dtype ? launch_conv2d_s2_t<BF16, 4, false>(p, st) : launch_conv2d_s2_t<F32, 4, false>(p, st);
+#define S2_CASE(TRT) do { if (nfs == 4) return launch_conv2d_s2_t<TRT, 4, true>(p, st); if (nfs == 2) return launch_conv2d_s2_t<TRT, 2, true>(p, st); return launch_conv2d_s2_t<TRT, 1, true>(p, st); } while (0)
         if (dtype) S2_CASE(BF16); else S2_CASE(F32);
 #undef S2_CASE
     }
