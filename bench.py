@@ -209,6 +209,8 @@ def main():
     ap.add_argument("--channels", default="16,32,64,128,256")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-reference-network", action="store_true",
+                    help="skip the side measurement on the channel widths of reference/train.py:82 (32-512)")
     ap.add_argument("--no-overlap", action="store_true", help="all-reduce after the whole backward")
     ap.add_argument("--host-input", action="store_true",
                     help="train mode: every step's batch starts in pinned host memory (fp32 image and label) and is copied "
@@ -461,6 +463,31 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
+
+    if (rank == 0 and world == 1 and not args.no_reference_network and args.dims == 2 and args.dtype == "bf16"
+            and args.channels == "16,32,64,128,256"):
+        # the same step on the channel widths reference/train.py:82 itself builds (four times the convolution work);
+        # a side figure, never `value`
+        ref_ch = (32, 64, 128, 256, 512)
+        torch.manual_seed(0)
+        m2 = unet_amd.UNet(2, 1, 1, ref_ch, (2, 2, 2, 2), num_res_units=2, dropout=args.dropout, compute_dtype=dtype).to(dev).train()
+        o2 = unet_amd.AdamW(m2.parameters(), lr=5e-4, weight_decay=1e-5, model=m2)
+        t2 = unet_amd.Trainer(m2, loss, o2)
+        n2 = max(3, min(args.steps, 10))
+        for _ in range(3):
+            t2.step(x, t)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n2):
+            t2.step(x, t)
+        torch.cuda.synchronize()
+        e2 = time.perf_counter() - t0
+        p2 = m2._plan_for(x, True)
+        f2 = p2.flops(False) + p2.flops(True)
+        out["reference_network"] = {"channels": "-".join(map(str, ref_ch)), "value": round(args.batch * n2 / e2, 2), "unit": "slices/s",
+                                    "steps": n2, "ms_per_step": round(1e3 * e2 / n2, 4),
+                                    "conv_gflop_per_step_per_gpu": round(f2 / 1e9, 1),
+                                    "conv_tflops_whole_step": round(f2 / (e2 / n2) / 1e12, 1)}
 
     if rank == 0:
         print(json.dumps(out), flush=True)

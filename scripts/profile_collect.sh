@@ -3,7 +3,8 @@
 #   pmc   : FETCH_SIZE and WRITE_SIZE passes (one counter per pass)
 #   sq    : one pass of eight SQ counters on a single stream
 #   trace : kernel traces (single stream and production schedule) and bench.py's own tables
-#   alt   : the secondary workloads (3-D training, sliding-window inference): kernel stats, bench JSON, per-layer table
+#   alt   : the secondary workloads (3-D training, sliding-window inference, the 32-512 channel widths of
+#           reference/train.py:82): kernel stats, bench JSON, per-layer table
 set -o pipefail
 STAGE=${1:-trace}
 OUT=gpurun_out/prof
@@ -23,8 +24,8 @@ elif [ "$STAGE" = sq ]; then
   cp "$(find $OUT/sq -name '*counter_collection.csv' | head -1)" $OUT/pmc_sq.csv || exit 1
   rm -rf $OUT/sq
 elif [ "$STAGE" = alt ]; then
-  for w in 3d infer; do
-    if [ $w = 3d ]; then ARGS="--dims 3 --size 96 --batch 4"; else ARGS="--mode infer"; fi
+  for w in 3d infer ref; do
+    if [ $w = 3d ]; then ARGS="--dims 3 --size 96 --batch 4"; elif [ $w = ref ]; then ARGS="--channels 32,64,128,256,512"; else ARGS="--mode infer"; fi
     rm -rf $OUT/a_$w
     timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $OUT/a_$w -o r --output-format csv -- python3 bench.py $ARGS --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing > $OUT/trace_$w.log 2>&1 || exit 1
     cp "$(find $OUT/a_$w -name '*kernel_stats.csv' | head -1)" $OUT/kernel_stats_$w.csv || exit 1
