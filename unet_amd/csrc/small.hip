@@ -176,15 +176,17 @@ __global__ __launch_bounds__(256) void c1_s2_fwd_kernel(const C1Params p) {
 // group g + 1 are requested before group g is multiplied (consecutive groups share one input row: 2 ROWS new rows
 // each), and the loads are unconditional (only fine row -1 and fine column -1 fall outside: the address is clamped and
 // the value replaced by zero).
-template <class TR, int ROWS, int NG>
+template <class TR, int ROWS, int NG, int N>     // N = 32 or 64 output channels: 4 or 8 lanes (channel groups of eight) per column
 __global__ __launch_bounds__(256) void c1_s2_fwd32_kernel(const C1Params p) {
     constexpr int ESZ = TR::ESZ;
-    constexpr int N = 32, NR = 2 * ROWS + 1;
+    constexpr int NR = 2 * ROWS + 1;
+    constexpr int NGRP = N / 8, COLS = 256 / NGRP;
+    static_assert(N == 32 || N == 64, "four or eight channel groups per column");
     __shared__ __attribute__((aligned(16))) float wl[9 * N];
     __shared__ float sst[2 * 16 * N];
-    const int grp = threadIdx.x & 3, pl = threadIdx.x >> 2;
+    const int grp = threadIdx.x % NGRP, pl = threadIdx.x / NGRP;
     const int img = blockIdx.z;
-    const int cx = blockIdx.x * 64 + pl;
+    const int cx = blockIdx.x * COLS + pl;
     const bool lane_ok = cx < p.cd[2];
     const int H = p.fd[1], W = p.fd[2];
     const size_t cpix = (size_t)p.cd[1] * p.cd[2];
@@ -277,18 +279,19 @@ __global__ __launch_bounds__(256) void c1_s2_fwd32_kernel(const C1Params p) {
         }
     }
     if (p.stats) {
-        // four channel groups per column: a 16-lane row holds four columns, two DPP row shifts add them up in lanes
-        // 12..15; the 16 rows of the workgroup then meet in LDS ([2][16 rows][N]), fixed order, then fp64 accumulators
+        // NGRP channel groups per column: a 16-lane row holds 16 / NGRP columns, DPP row shifts (by 4 and 8 lanes, or by
+        // 8) add them up in its last NGRP lanes; the 16 rows of the workgroup then meet in LDS ([2][16 rows][N]), fixed
+        // order, then fp64 accumulators
         const int slot = (blockIdx.x + blockIdx.y) % MI_NSLOT;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            s1[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1[e]), 0x114, 0xf, 0xf, true));
+            if (NGRP == 4) s1[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1[e]), 0x114, 0xf, 0xf, true));
             s1[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1[e]), 0x118, 0xf, 0xf, true));
-            s2[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s2[e]), 0x114, 0xf, 0xf, true));
+            if (NGRP == 4) s2[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s2[e]), 0x114, 0xf, 0xf, true));
             s2[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s2[e]), 0x118, 0xf, 0xf, true));
         }
         const int row = threadIdx.x >> 4;
-        if ((threadIdx.x & 15) >= 12) {
+        if ((threadIdx.x & 15) >= 16 - NGRP) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 sst[row * N + grp * 8 + e] = s1[e];
@@ -891,12 +894,14 @@ int run_c1_fwd(const C1Params& p, hipStream_t st) {
     constexpr int KK = KZ * 9, ROWS = 4;
     const int ppb = 256 / (p.N / 8);
     const size_t lds = (size_t)(p.N * KK + 2 * ppb * p.N) * sizeof(float);
-    if (KZ == 1 && p.N == 32 && (size_t)p.fd[1] * p.fd[2] < (1u << 30) && p.fd[2] >= 2 * p.cd[2] && p.fd[1] >= 1) {
+    if (KZ == 1 && (p.N == 32 || p.N == 64) && (size_t)p.fd[1] * p.fd[2] < (1u << 30) && p.fd[2] >= 2 * p.cd[2] && p.fd[1] >= 1) {
         static const bool strip = getenv("MI_NO_C1_STRIP") == nullptr;
         if (strip) {
             constexpr int R2 = 4, G2 = 8;      // 32 coarse rows per workgroup
-            dim3 grid((p.cd[2] + 63) / 64, (p.cd[1] + R2 * G2 - 1) / (R2 * G2), p.nb);
-            hipLaunchKernelGGL((c1_s2_fwd32_kernel<TR, R2, G2>), grid, dim3(256), 0, st, p);
+            const int cols = p.N == 32 ? 64 : 32;
+            dim3 grid((p.cd[2] + cols - 1) / cols, (p.cd[1] + R2 * G2 - 1) / (R2 * G2), p.nb);
+            if (p.N == 32) hipLaunchKernelGGL((c1_s2_fwd32_kernel<TR, R2, G2, 32>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((c1_s2_fwd32_kernel<TR, R2, G2, 64>), grid, dim3(256), 0, st, p);
             return check_launch("c1_s2_fwd32");
         }
     }
