@@ -32,10 +32,10 @@ def label(name: str) -> str:
         return f"wgrad_kernel<{tr},{','.join(rest)}>"
     if kern == "wgrad_dma_kernel":           # same step label as the register-staged kernel it stands in for
         return f"wgrad_kernel<{tr},{','.join(rest[:5])}>"
+    if kern == "conv2d_s2_kernel" and len(rest) > 1 and rest[1] == "false":    # tap tiles streamed with the patches
+        return f"{kern}<{tr},{rest[0]},streamed>"
     if kern in ("conv2d_dma_kernel", "conv2d_phase_kernel", "conv2d_s2_kernel"):
         return f"{kern}<{tr},{rest[0]}>"
-    if kern == "conv2d_dma_kernel":
-        return f"conv2d_dma_kernel<{tr},{rest[0]}>"
     return f"{kern}<{tr}>"
 
 
