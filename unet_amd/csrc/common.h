@@ -169,6 +169,24 @@ __device__ __forceinline__ bool dropout_keep1(const DropKeys& k, unsigned idx) {
 // ---- host side ----------------------------------------------------------------
 #include <string>
 void mi_set_error(const std::string& s);
+// hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) once per (kernel, device) and size
+// instead of on every launch: the call takes a runtime lock and is a measurable share of the host time of a step
+// whose kernels are short.
+#include <map>
+#include <mutex>
+inline hipError_t mi_func_set_lds(const void* kern, int bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, int> granted;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    int& cur = granted[std::make_pair(kern, dev)];
+    if (bytes <= cur) return hipSuccess;
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) cur = bytes;
+    return e;
+}
 #define MI_CHECK(cond, msg)                                   \
     do {                                                      \
         if (!(cond)) {                                        \

@@ -583,7 +583,7 @@ int launch_conv2d_phase_t(const IgemmParams& pin, hipStream_t st) {
     p.tpw = tiles_per_wg(p, NT);
     auto kern = conv2d_phase_kernel<TR, NFRAG>;
     if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = mi_func_set_lds(reinterpret_cast<const void*>(kern), (int)lds);
         if (e != hipSuccess) { mi_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return -2; }
     }
     dim3 grid(p.nb * p.ntile[1] * p.ntile[2] / p.tpw, p.N / NT, 1);
@@ -795,7 +795,7 @@ int launch_conv2d_s2_t(const IgemmParams& pin, hipStream_t st) {
     p.tpw = tiles_per_wg(p, NT);
     auto kern = conv2d_s2_kernel<TR, NFRAG, WRES>;
     if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = mi_func_set_lds(reinterpret_cast<const void*>(kern), (int)lds);
         if (e != hipSuccess) { mi_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return -2; }
     }
     dim3 grid(p.nb * p.ntile[1] * p.ntile[2] / p.tpw, p.N / NT, 1);
@@ -1141,7 +1141,7 @@ int launch_conv2d_t(const IgemmParams& pin, hipStream_t st) {
     }
     auto kern = conv2d_dma_kernel<TR, NFRAG, KS, WRES>;
     if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = mi_func_set_lds(reinterpret_cast<const void*>(kern), (int)lds);
         if (e != hipSuccess) { mi_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return -2; }
     }
     dim3 grid(p.nb * tiles_img / p.tpw, p.N / NT, 1);

@@ -1049,8 +1049,7 @@ template <class K>
 int set_lds(K kern, size_t bytes) {
     if (bytes > 160 * 1024) { mi_set_error("LDS request exceeds 160 KiB"); return -1; }
     if (bytes > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        hipError_t e = mi_func_set_lds(reinterpret_cast<const void*>(kern), (int)bytes);
         if (e != hipSuccess) { mi_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return -2; }
     }
     return 0;

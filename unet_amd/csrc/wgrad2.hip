@@ -346,7 +346,7 @@ int launch_wgrad_dma_t(const WgradParams& p, int nis, hipStream_t st) {
     if (lds > 160 * 1024) return 1;
     auto kern = wgrad_dma_kernel<TR, NT, FF, SF, WF, WS, NISW>;
     if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = mi_func_set_lds(reinterpret_cast<const void*>(kern), (int)lds);
         if (e != hipSuccess) { mi_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return -2; }
     }
     dim3 grid(p.nsplit, p.F / FB, (p.S / (16 * SF * WS)) * p.ntapg);

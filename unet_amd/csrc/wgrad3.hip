@@ -763,7 +763,7 @@ static int launch_wgrad_thin(int dtype, const WgradParams& p, int ff, int sf, in
     const size_t lds = (size_t)R * (8 + 12) * 1024;
     static bool done = false;
     if (!done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_thin_kernel<2, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = mi_func_set_lds(reinterpret_cast<const void*>(wgrad_thin_kernel<2, R>), (int)lds);
         if (e != hipSuccess) { mi_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return -2; }
         done = true;
     }
@@ -787,7 +787,7 @@ int launch_wgrad_thick(int dtype, const WgradParams& p, int ff, int sf, int wf, 
         auto kern2 = sf == 2 ? wgrad_thick_s2_kernel<2> : wgrad_thick_s2_kernel<1>;
         static bool attr2[2] = {false, false};
         if (!attr2[sf - 1]) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            hipError_t e = mi_func_set_lds(reinterpret_cast<const void*>(kern2), (int)lds2);
             if (e != hipSuccess) { mi_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return -2; }
             attr2[sf - 1] = true;
         }
@@ -800,7 +800,7 @@ int launch_wgrad_thick(int dtype, const WgradParams& p, int ff, int sf, int wf, 
     constexpr size_t lds = 2 * (16 + 23) * 1024;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_thick_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = mi_func_set_lds(reinterpret_cast<const void*>(wgrad_thick_kernel), (int)lds);
         if (e != hipSuccess) { mi_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return -2; }
         attr_done = true;
     }

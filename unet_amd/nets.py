@@ -354,10 +354,13 @@ class UNet(nn.Module):
             self._ptable_ordered = [by_name[n] for n in names]
         return self._ptable
 
-    def _ensure_flat(self, device):
-        """Keeps every parameter a view into one flat fp32 buffer (what the engine and AdamW read)."""
+    def _ensure_flat(self, device, params=None):
+        """Keeps every parameter a view into one flat fp32 buffer (what the engine and AdamW read).  ``params``: the
+        model's Parameter objects in ``parameters()`` order when the caller already holds them (an optimizer does, as
+        ``torch.optim`` optimizers do: walking the module tree costs more host time than enqueueing ten kernels)."""
         self._layout()
-        params = list(self.parameters())
+        if params is None:
+            params = list(self.parameters())
         flat = self._flat
         ok = flat is not None and flat.device == device
         if ok:

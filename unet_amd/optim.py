@@ -35,7 +35,20 @@ class AdamW(torch.optim.Optimizer):
 
     def bind(self, model):
         self._model = model
+        self._owned = None
         return self
+
+    def _params_of(self, model):
+        """This optimizer's parameter list, checked once to be exactly ``model.parameters()`` (same objects, same
+        order).  Like any ``torch.optim`` optimizer it keeps updating these objects, whatever is assigned to the
+        module's attributes later."""
+        params = self.param_groups[0]["params"]
+        if getattr(self, "_owned", None) is not model:
+            mp = list(model.parameters())
+            if len(params) != len(mp) or any(a is not b for a, b in zip(params, mp)):
+                raise RuntimeError("unet_amd.AdamW must own exactly the parameters of its UNet")
+            self._owned = model
+        return params
 
     def _flat_grad(self, model, flat):
         """Returns a flat gradient laid out like ``flat``: the buffer the last backward produced when every
@@ -99,7 +112,7 @@ class AdamW(torch.optim.Optimizer):
         self._m, self._v, self._step = m, v, steps.pop()
 
     @torch.no_grad()
-    def step(self, closure=None, *, flat_grad=None, grad_scale: float = 1.0):
+    def step(self, closure=None, *, flat_grad=None, grad_scale: float = 1.0, flat=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -107,10 +120,9 @@ class AdamW(torch.optim.Optimizer):
         model = self._model
         if model is None:
             raise RuntimeError("unet_amd.AdamW: call bind(model) or pass model= at construction")
-        params = self.param_groups[0]["params"]
-        if len(params) != len(model._layout()):
-            raise RuntimeError("unet_amd.AdamW must own exactly the parameters of its UNet")
-        flat = model._ensure_flat(params[0].device)
+        if flat is None:                # ``flat``: the caller has just validated the flat parameter buffer itself
+            params = self._params_of(model)
+            flat = model._ensure_flat(params[0].device, params)
         if not flat.is_cuda:
             raise RuntimeError("unet_amd.AdamW runs on an AMD GPU only (no CPU or eager fallback)")
         g = flat_grad if flat_grad is not None else self._flat_grad(model, flat)

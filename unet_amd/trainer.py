@@ -80,7 +80,7 @@ class Trainer:
         if labels.shape != x.shape:
             raise AssertionError(f"ground truth has different shape ({labels.shape}) from input ({x.shape})")
         dev = x.device
-        flat = model._ensure_flat(dev)
+        flat = model._ensure_flat(dev, self.opt._params_of(model))
         b = self._buffers(x)
         plan = b["plan"]
         if self._grad is None or self._grad.device != dev:
@@ -113,4 +113,4 @@ class Trainer:
                 for bucket in range(3):
                     self._reducer.launch(bucket)
                 self._reducer.wait()
-        self.opt.step(flat_grad=self._grad, grad_scale=1.0 / self.world)
+        self.opt.step(flat_grad=self._grad, grad_scale=1.0 / self.world, flat=flat)
