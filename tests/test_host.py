@@ -345,3 +345,21 @@ def test_strip_convolution_addresses_stay_inside_the_tensors(shape, rows_groups)
                             lo, hi = min(lo, idx), max(hi, idx)
     assert lo >= 0 and hi < nb * H * W
     assert len(stores) == nb * cd1 * cd2
+
+
+def test_optimizer_parameter_list_is_checked_once_and_reused():
+    """unet_amd.AdamW hands its own parameter list to the flat-buffer check instead of walking the module tree
+    every step; the list must be exactly model.parameters() (same objects, same order), which is verified when
+    it is first used for a model."""
+    m = unet_amd.UNet(**dict(CFG, channels=(16, 32, 64), strides=(2, 2)))
+    opt = unet_amd.AdamW(m.parameters(), lr=1e-3, model=m)
+    params = opt._params_of(m)
+    assert len(params) == len(list(m.parameters())) and all(a is b for a, b in zip(params, m.parameters()))
+    assert opt._params_of(m) is params                      # second use: no walk, same list
+    flat = m._ensure_flat(torch.device("cpu"), params)       # parameters become views of one buffer, in engine order
+    assert all(p.data_ptr() >= flat.data_ptr() and p.data_ptr() < flat.data_ptr() + 4 * flat.numel() for p in params)
+    other = unet_amd.UNet(**dict(CFG, channels=(16, 32, 64), strides=(2, 2)))
+    with pytest.raises(RuntimeError):
+        unet_amd.AdamW(list(m.parameters())[:-1], lr=1e-3, model=m)._params_of(m)
+    with pytest.raises(RuntimeError):
+        opt.bind(other)._params_of(other)                    # another model's parameters
