@@ -1166,8 +1166,10 @@ void igemm_config(int dtype, const IgemmParams& p, int* cps, int* nfrag) {
     if (c == 4 && igemm_lds_for(p, c, nf) > kLdsBudget) c = 2;
     while (nf > 1 && igemm_lds_for(p, c, nf) > kLdsBudget) nf >>= 1;
     {
-        // small problems: narrower channel tiles until there is about one workgroup per CU
-        int min_wgs = 256;
+        // small problems: narrower channel tiles until there is about one workgroup per CU (2-D) or per four CUs
+        // (3-D: a narrower tile stages the same 3-D patch, ten times the size of a 2-D one, once more per channel
+        // block; measured on 96^3 patches: 1.846 -> 1.803 ms per step, the 2-D small-batch case prefers 256)
+        int min_wgs = p.id[0] > 1 ? 64 : 256;
         if (const char* e = getenv("MI_IGEMM_MIN_WGS")) min_wgs = atoi(e);
         const long long tiles = (long long)p.nb * p.ntile[0] * p.ntile[1] * p.ntile[2] * p.nphase;
         while (nf > 1 && tiles * (p.N / (16 * nf)) < min_wgs) nf >>= 1;
