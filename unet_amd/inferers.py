@@ -79,6 +79,22 @@ def _windows_per_call(predictor, sw_batch_size: int, total: int, window_elems: i
     return n, False
 
 
+_STARTS_CACHE: dict = {}
+
+
+def _starts_on_device(st3, dev):
+    """Window origins as an int32 tensor on ``dev``, kept per (origins, device): a validation loop asks for the same
+    few placements again and again, and a pageable host-to-device copy per call would stall the host behind the GPU."""
+    key = (st3, dev.type, dev.index)
+    t = _STARTS_CACHE.get(key)
+    if t is None:
+        if len(_STARTS_CACHE) >= 64:
+            _STARTS_CACHE.clear()
+        t = torch.tensor(st3, dtype=torch.int32).to(dev)
+        _STARTS_CACHE[key] = t
+    return t
+
+
 def sliding_window_inference(inputs: torch.Tensor, roi_size, sw_batch_size: int,
                              predictor: Callable[[torch.Tensor], torch.Tensor], overlap: float = 0.25,
                              mode: str = "constant", sigma_scale=0.125, padding_mode: str = "constant",
@@ -106,8 +122,8 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size, sw_batch_size: int,
     nwin = len(starts)
     total = nwin * nb
     dev = x.device
-    st3 = [(0,) * (3 - nd) + tuple(s) for s in starts]
-    starts_dev = torch.tensor(st3, dtype=torch.int32).to(dev)
+    st3 = tuple((0,) * (3 - nd) + tuple(s) for s in starts)
+    starts_dev = _starts_on_device(st3, dev)
     I3 = C.c_int32 * 3
     img3 = I3(*([1] * (3 - nd) + img))
     roi3 = I3(*([1] * (3 - nd) + roi))
@@ -115,7 +131,7 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size, sw_batch_size: int,
     rpix = 1
     for r in roi:
         rpix *= r
-    win_out = torch.empty((total, 1) + tuple(roi), dtype=torch.float32, device=dev)
+    win_out = None
     stream = _lib.current_stream(dev)
     group, pad_tail = _windows_per_call(predictor, sw_batch_size, total, rpix)
     for g in range(0, total, group):
@@ -131,7 +147,12 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size, sw_batch_size: int,
             pred = pred[0]
         if pred.shape != wins.shape:
             raise NotImplementedError("the predictor must keep the window shape (one output channel)")
-        win_out[g:g + n].copy_(pred[:n])
+        if n == total and pred.dtype == torch.float32 and pred.is_contiguous():
+            win_out = pred                  # one group holds every window: blend straight from the predictor's output
+        else:
+            if win_out is None:
+                win_out = torch.empty((total, 1) + tuple(roi), dtype=torch.float32, device=dev)
+            win_out[g:g + n].copy_(pred[:n])
     out = torch.empty((nb, 1) + tuple(img), dtype=torch.float32, device=dev)
     _lib.check(lib.mi_sw_blend(win_out.data_ptr(), out.data_ptr(), starts_dev.data_ptr(), nwin, nb, img3, roi3, pad3,
                                stream), "mi_sw_blend")

@@ -352,7 +352,17 @@ class UNet(nn.Module):
                 if tuple(p.shape) != by_name[n][1]:
                     raise RuntimeError(f"shape mismatch for {n}: {tuple(p.shape)} vs {by_name[n][1]}")
             self._ptable_ordered = [by_name[n] for n in names]
+            # where every parameter lives, in parameters() order: (owning module, attribute name).  The module tree is
+            # fixed by the constructor (the engine's layout follows it); reading the slots returns the Parameter
+            # objects now assigned, without walking the tree (130 us of host time per walk).
+            owners = dict(self.named_modules())
+            self._param_slots = [(owners[n.rpartition(".")[0]], n.rpartition(".")[2]) for n in names]
         return self._ptable
+
+    def _params_now(self):
+        """The model's Parameter objects in ``parameters()`` order."""
+        self._layout()
+        return [m._parameters[k] for m, k in self._param_slots]
 
     def _ensure_flat(self, device, params=None):
         """Keeps every parameter a view into one flat fp32 buffer (what the engine and AdamW read).  ``params``: the
@@ -430,8 +440,9 @@ class UNet(nn.Module):
         xin = xin.contiguous()
         if xin.dtype != torch.float32:
             xin = xin.float()
-        self._ensure_flat(xin.device)
-        params = list(self.parameters())
+        params = self._params_now()
+        self._ensure_flat(xin.device, params)
         need_bwd = torch.is_grad_enabled() and any(p.requires_grad for p in params)
-        out = _UNetFunction.apply(self, need_bwd, xin, *params)
+        # without a backward pass the parameters need not travel through the autograd function's argument list
+        out = _UNetFunction.apply(self, need_bwd, xin, *params) if need_bwd else _UNetFunction.apply(self, False, xin)
         return out if in_dtype == torch.float32 else out.to(in_dtype)
