@@ -1158,7 +1158,8 @@ void igemm_config(int dtype, const IgemmParams& p, int* cps, int* nfrag) {
     const int kce4 = 64 / esz;
     int c = (p.K % kce4 == 0 && (p.in0_c >= p.K || p.in0_c % kce4 == 0)) ? 4 : 2;
     int nf = (p.N % 64 == 0) ? 4 : (p.N % 32 == 0) ? 2 : 1;
-    if (!getenv("MI_NO_IGEMM2D") && igemm2d_ks(p) == 3 && p.sa == 2) {
+    static const bool no_igemm2d = getenv("MI_NO_IGEMM2D") != nullptr;     // read once: this runs on every launch
+    if (!no_igemm2d && igemm2d_ks(p) == 3 && p.sa == 2) {
         // 33 x 33 patch: 32-byte chunks; with at most 64 output channels two 32-channel workgroups fit a CU
         c = 2;
         if (nf > 2 && p.N <= 64) nf = 2;
@@ -1170,7 +1171,8 @@ void igemm_config(int dtype, const IgemmParams& p, int* cps, int* nfrag) {
         // (3-D: a narrower tile stages the same 3-D patch, ten times the size of a 2-D one, once more per channel
         // block; measured on 96^3 patches: 1.846 -> 1.803 ms per step, the 2-D small-batch case prefers 256)
         int min_wgs = p.id[0] > 1 ? 64 : 256;
-        if (const char* e = getenv("MI_IGEMM_MIN_WGS")) min_wgs = atoi(e);
+        static const int min_wgs_env = getenv("MI_IGEMM_MIN_WGS") ? atoi(getenv("MI_IGEMM_MIN_WGS")) : 0;
+        if (min_wgs_env > 0) min_wgs = min_wgs_env;
         const long long tiles = (long long)p.nb * p.ntile[0] * p.ntile[1] * p.ntile[2] * p.nphase;
         while (nf > 1 && tiles * (p.N / (16 * nf)) < min_wgs) nf >>= 1;
     }
@@ -1208,9 +1210,11 @@ int launch_igemm(int dtype, const IgemmParams& p, hipStream_t st) {
     MI_CHECK((long long)p.nb * p.od[0] * p.od[1] * p.od[2] < (1ll << 31) && (long long)p.nb * p.id[0] * p.id[1] * p.id[2] < (1ll << 31),
              "tensor has too many pixels for 32-bit pixel indices");
     MI_CHECK(p.ksplit <= 1 || (p.kpart != nullptr && p.N % 4 == 0 && p.N / 4 <= 256), "contraction split needs a partial-sum buffer");
-    const int ks = (getenv("MI_NO_IGEMM2D") || p.ksplit > 1) ? 0 : igemm2d_ks(p);
+    static const bool no_igemm2d = getenv("MI_NO_IGEMM2D") != nullptr;
+    const int ks = (no_igemm2d || p.ksplit > 1) ? 0 : igemm2d_ks(p);
     int phl_max = 2;   // widest channel tile (in 16-channel fragments) that loops over the scatter phases in one workgroup
-    if (const char* e = getenv("MI_PHL_MAX")) phl_max = atoi(e);
+    static const int phl_env = getenv("MI_PHL_MAX") ? atoi(getenv("MI_PHL_MAX")) : -1;
+    if (phl_env >= 0) phl_max = phl_env;
 #define IG_CASE(TRT, C, NF)                                                  \
     if (cps == C && nfrag == NF) {                                           \
         if (ks == 3 && p.sa == 2 && C == 2) return launch_igemm2d_t<TRT, 2, NF, 3, 2>(p, st); \
@@ -1244,7 +1248,8 @@ void wgrad_config(int dtype, const WgradParams& p, int* ff, int* sf, int* wf, in
     if (wgrad_thick_config(dtype, p, ff, sf, wf, wsn)) return;
     auto pick = [](int c, int maxblk) { int b = maxblk; while (b > 16 && c % b) b >>= 1; return b; };
     int maxb = dtype ? 64 : 32;
-    if (const char* e = getenv("MI_WG_MAXB")) { const int v = atoi(e); if (v >= 16 && v < maxb) maxb = v; }
+    static const int maxb_env = getenv("MI_WG_MAXB") ? atoi(getenv("MI_WG_MAXB")) : 0;
+    if (maxb_env >= 16 && maxb_env < maxb) maxb = maxb_env;
     int FB = pick(p.F, maxb), SB = pick(p.S, maxb);
     if (p.f0_c < p.F) while (FB > 16 && p.f0_c % FB) FB >>= 1;
     while (wgrad_lds_for(dtype, p, FB, SB) > kLdsBudget && (SB > 16 || FB > 16)) {
@@ -1264,7 +1269,8 @@ void wgrad_choose_split(int dtype, WgradParams& p, int target) {
     // default: three quarters of the CUs.  A weight gradient runs next to the kernels of the critical chain; with
     // more workgroups it finishes sooner and slows them by more than it gains (measured 192 < 256 << 512).
     if (target <= 0) target = 192;
-    if (const char* e = getenv("MI_WG_WGS")) { const int v = atoi(e); if (v > 0) target = v; }
+    static const int wgs_env = getenv("MI_WG_WGS") ? atoi(getenv("MI_WG_WGS")) : 0;
+    if (wgs_env > 0) target = wgs_env;
     int nsplit = (target + blocks - 1) / blocks;
     if (nsplit > p.tiles_total) nsplit = p.tiles_total;
     if (nsplit < 1) nsplit = 1;
