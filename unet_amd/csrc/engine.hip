@@ -54,6 +54,8 @@ struct Step {
     AddArgs add; MemsetArgs ms; TabArgs tab;
     std::vector<Reloc> rel;
     double total_ms = 0; long long launches = 0;
+    int wait_pack = 0;     // forward: this step is the first to read packed weights (waits for the first packing launch)
+    int join_side = 0;     // forward: this step is the first to read weights of the second packing launch (joins the side stream)
     Step() {
         memset(&ig, 0, sizeof(ig)); memset(&wg, 0, sizeof(wg)); memset(&nm, 0, sizeof(nm));
         memset(&c1, 0, sizeof(c1)); memset(&stn, 0, sizeof(stn)); memset(&add, 0, sizeof(add));
@@ -117,6 +119,7 @@ struct mi_unet {
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> side_ev;      // one "inputs ready" event per weight-gradient step, then one join event
     hipEvent_t join_ev = nullptr;
+    hipEvent_t pack_ev = nullptr;         // forward: the first packing launch (weights of the first levels) is done
     int use_side = -1;                    // -1: undecided, 0: off, 1: on
     // profiling
     bool prof = false;
@@ -473,13 +476,21 @@ bool build(mi_unet& u) {
         Step& s = B.push(u.fwd, K_MEMSET, "clear forward statistics");
         REL(s, s.ms, ptr, B_ARENA, u.off_stats); s.ms.bytes = 0;  // bytes patched after the build
         s.kernel = "hipMemsetAsync";
-        Step& p = B.push(u.fwd, K_PACK, "pack weights");
+        // Weight packing runs beside the first layers in two launches: the weights of the first encoder levels (few),
+        // which the first MFMA convolution waits for, and everything else (the deep levels hold nearly all
+        // parameters), which the first deep layer joins.  The split point is patched in after the build.
+        Step& p = B.push(u.fwd, K_PACK, "pack weights (first levels)");
         p.kernel = dt ? "pack_kernel<BF16>" : "pack_kernel<F32>";
+        Step& q = B.push(u.fwd, K_PACK, "pack weights");
+        q.kernel = p.kernel;
     }
+    constexpr int PACK_CUT_LEVEL = 3;              // encoder levels below this one belong to the first launch
+    int packs_first = -1; size_t first_rest_step = 0;
     for (int l = 0; l <= L - 2; ++l) {
         const int cin = l == 0 ? 1 : c[l - 1], cout = c[l];
         const std::string P = dprefix[l];
         const std::string lname = "down" + std::to_string(l);
+        if (l == PACK_CUT_LEVEL) { packs_first = (int)u.packs.size(); first_rest_step = u.fwd.size(); }
         DownSave& D = down[l];
         D.raw0 = B.new_tensor(l + 1, cout, esz);   // unit0 conv output (before the norm)
         D.res = B.new_tensor(l + 1, cout, esz);    // residual conv output
@@ -540,6 +551,7 @@ bool build(mi_unet& u) {
         }
     }
     // ---- bottom ----
+    if (packs_first < 0) { packs_first = (int)u.packs.size(); first_rest_step = u.fwd.size(); }
     {
         const int cin = c[L - 2], cout = c[L - 1], res = L - 1;
         const std::string P = botprefix;
@@ -908,13 +920,23 @@ bool build(mi_unet& u) {
                 ++k;
             }
     }
-    for (Step& s : u.fwd) {
-        if (s.kind == K_PACK) {
-            s.tab.first = 0; s.tab.count = (int)u.packs.size();  // forward and backward packs in one launch
-            if (!train) s.tab.count = n_fwd_packs;
-            for (int i = 0; i < s.tab.count; ++i) u.packs[i].nblk = pack_blocks_for(u.packs[i].N * u.packs[i].K);
+    {
+        // first packing launch: descriptors [0, packs_first); second: the rest (forward and backward packs in one launch)
+        const int total = train ? (int)u.packs.size() : n_fwd_packs;
+        int npack = 0;
+        bool first_igemm = true;
+        for (size_t i = 0; i < u.fwd.size(); ++i) {
+            Step& s = u.fwd[i];
+            if (s.kind == K_PACK) {
+                if (npack++ == 0) { s.tab.first = 0; s.tab.count = packs_first; }
+                else { s.tab.first = packs_first; s.tab.count = total - packs_first; }
+                for (int j = s.tab.first; j < s.tab.first + s.tab.count; ++j) u.packs[j].nblk = pack_blocks_for(u.packs[j].N * u.packs[j].K);
+            }
+            if (s.kind == K_IGEMM && first_igemm) { s.wait_pack = 1; first_igemm = false; }
+            if (i == first_rest_step) s.join_side = 1;
+            if (s.kind == K_MEMSET) s.ms.bytes = align_up(B.stats_cursor, 16);
         }
-        if (s.kind == K_MEMSET) s.ms.bytes = align_up(B.stats_cursor, 16);
+        if (first_rest_step >= u.fwd.size() || u.fwd[first_rest_step].kind != K_IGEMM) { mi_set_error("packing split: no convolution at the split point"); return false; }
     }
     for (Step& s : u.bwd)
         if (s.kind == K_MEMSET) s.ms.bytes = align_up(B.bstats_cursor, 16);
@@ -1016,11 +1038,13 @@ int run_list(mi_unet& u, std::vector<Step>& list, int backward, int bucket, char
             if (u.use_side) {
                 if (hipStreamCreateWithFlags(&u.side, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); u.use_side = 0; }
                 else if (hipEventCreateWithFlags(&u.join_ev, fork_event_flags()) != hipSuccess) { (void)hipGetLastError(); u.use_side = 0; }
+                else if (hipEventCreateWithFlags(&u.pack_ev, fork_event_flags()) != hipSuccess) { (void)hipGetLastError(); u.use_side = 0; }
             }
         }
         side = u.use_side == 1;
     }
     bool pending = false;
+    bool pack_first_pending = false, pack_first_done = false;
     size_t nside = 0;
     auto fork = [&]() -> int {      // the side stream waits for everything enqueued on the main stream so far
         if (nside >= u.side_ev.size()) {
@@ -1049,11 +1073,19 @@ int run_list(mi_unet& u, std::vector<Step>& list, int backward, int bucket, char
         }
         const bool on_side = side && (backward ? (is_wgrad_kind(s.kind) || s.kind == K_REDUCE) : s.kind == K_PACK);
         if (on_side) {
-            if (int r = fork()) return r;
+            if (backward || !pack_first_pending) { if (int r = fork()) return r; }     // the second packing launch follows the first
             if (int r = run_step(u, s, bases, training, seed, u.side)) return r;
+            if (!backward && !pack_first_pending && !pack_first_done) {
+                MI_HIP(hipEventRecord(u.pack_ev, u.side));
+                pack_first_pending = true;
+            }
             pending = true;
         } else {
-            if (pending && !backward && s.kind == K_IGEMM) { if (int r = join()) return r; }
+            if (!backward && s.wait_pack && pack_first_pending) {
+                MI_HIP(hipStreamWaitEvent(st, u.pack_ev, 0));
+                pack_first_pending = false; pack_first_done = true;
+            }
+            if (!backward && s.join_side && pending) { if (int r = join()) return r; }
             if (int r = run_step(u, s, bases, training, seed, st)) return r;
         }
         if (u.prof) {
@@ -1114,6 +1146,7 @@ void mi_unet_destroy(mi_unet* u) {
     for (ProfEvent& e : u->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (hipEvent_t e : u->side_ev) (void)hipEventDestroy(e);
     if (u->join_ev) (void)hipEventDestroy(u->join_ev);
+    if (u->pack_ev) (void)hipEventDestroy(u->pack_ev);
     if (u->side) (void)hipStreamDestroy(u->side);
     delete u;
 }
