@@ -1,6 +1,6 @@
 """Host time to enqueue one training step against the GPU time of the step (no synchronisation inside the loop: when
 the first figure is the larger one the host is what bounds the step).
-usage: python scripts/host_enqueue.py [batch] [size] [dims]"""
+usage: python scripts/host_enqueue.py [batch] [size] [dims] [channels, e.g. 32,64,128,256,512]"""
 import os
 import sys
 import time
@@ -15,9 +15,10 @@ def main():
     batch = int(sys.argv[1]) if len(sys.argv) > 1 else 32
     size = int(sys.argv[2]) if len(sys.argv) > 2 else 512
     dims = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    channels = tuple(int(c) for c in sys.argv[4].split(",")) if len(sys.argv) > 4 else (16, 32, 64, 128, 256)
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
-    model = unet_amd.UNet(dims, 1, 1, (16, 32, 64, 128, 256), (2, 2, 2, 2), num_res_units=2, dropout=0.1,
+    model = unet_amd.UNet(dims, 1, 1, channels, (2,) * (len(channels) - 1), num_res_units=2, dropout=0.1,
                           compute_dtype=torch.bfloat16).to(dev).train()
     loss = unet_amd.DiceLoss(sigmoid=True, fold_label_two=True)
     opt = unet_amd.AdamW(model.parameters(), lr=5e-4, weight_decay=1e-5, model=model)
@@ -34,7 +35,7 @@ def main():
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
-    print(f"batch {batch} size {size} dims {dims}: host enqueue {1e3 * (t1 - t0) / n:.3f} ms/step, "
+    print(f"batch {batch} size {size} dims {dims} channels {channels[0]}-{channels[-1]}: host enqueue {1e3 * (t1 - t0) / n:.3f} ms/step, "
           f"enqueue + drain {1e3 * (t2 - t0) / n:.3f} ms/step")
 
 
