@@ -142,7 +142,7 @@ def test_fp32_realistic_slopes_and_reproducibility(dev, cfg):
         assert all(torch.equal(a, p.grad) for a, p in zip(first, m.parameters())), "gradients changed from run to run"
 
 
-@pytest.mark.parametrize("cfg", [CONFIGS[1], CONFIGS[3], CONFIGS[6]], ids=["2d_small", "2d_16-256", "3d_16-256"])
+@pytest.mark.parametrize("cfg", [CONFIGS[1], CONFIGS[3], CONFIGS[4], CONFIGS[6]], ids=["2d_small", "2d_16-256", "2d_32-512", "3d_16-256"])
 def test_bf16_close_to_oracle(dev, cfg):
     dims, channels, ru, nb, sp = cfg
     o, m = make_pair(dims, channels, ru, 0.0, torch.bfloat16, dev)
