@@ -169,6 +169,22 @@ __device__ __forceinline__ bool dropout_keep1(const DropKeys& k, unsigned idx) {
 // ---- host side ----------------------------------------------------------------
 #include <string>
 void mi_set_error(const std::string& s);
+// mean / rstd of a one-channel image from its fp64 statistics slots ([nb][NSLOT][2])
+__device__ __forceinline__ void c1_moments(const double* stats, int img, int npix, float eps, float& mean, float& rstd) {
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < MI_NSLOT; ++sl) {
+        s1 += stats[((size_t)img * MI_NSLOT + sl) * 2];
+        s2 += stats[((size_t)img * MI_NSLOT + sl) * 2 + 1];
+    }
+    const double m = s1 / (double)npix;
+    double var = s2 / (double)npix - m * m;
+    var = var > 0.0 ? var : 0.0;
+    mean = (float)m;
+    rstd = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+
 // hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) once per (kernel, device) and size
 // instead of on every launch: the call takes a runtime lock and is a measurable share of the host time of a step
 // whose kernels are short.

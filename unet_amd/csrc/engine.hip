@@ -643,19 +643,34 @@ bool build(mi_unet& u) {
                 s.work = (double)nb * (u.rp[0] * 4.0 + u.rp[1] * (double)K * esz);
                 u.flops_fwd += 2.0 * nb * u.rp[1] * KK * (double)K;
             }
-            B.add_norm_fwd(lname + ".convT norm+prelu", 0, 1, 0, U.rawT, U.statsT, P + ".0.adn.A.weight", nullptr, U.actT, U.lidT);
+            // The one-channel top: when the 2-D strip stencil serves the shape it reads the raw transposed-convolution
+            // output and normalises, drops and activates it on load (MI_NO_NORM_ON_LOAD=1: the separate pass); the
+            // activated tensor is written on the side when a backward pass will read it.
+            StencilParams probe; memset(&probe, 0, sizeof(probe));
+            probe.ndim = nd; for (int d = 0; d < 3; ++d) probe.d[d] = u.rd[0][d];
+            static const bool no_fuse = getenv("MI_NO_NORM_ON_LOAD") && atoi(getenv("MI_NO_NORM_ON_LOAD")) != 0;
+            const bool fuse_top = !no_fuse && stencil_norm_on_load_ok(probe);
+            if (fuse_top) B.record_norm(0, 1, 0, U.rawT, U.statsT, U.lidT);
+            else B.add_norm_fwd(lname + ".convT norm+prelu", 0, 1, 0, U.rawT, U.statsT, P + ".0.adn.A.weight", nullptr, U.actT, U.lidT);
             {
-                Step& s = B.push(u.fwd, K_STENCIL, lname + ".ru conv (1->1) + identity");
+                Step& s = B.push(u.fwd, K_STENCIL, lname + (fuse_top ? ".convT norm+prelu on load, ru conv (1->1) + identity" : ".ru conv (1->1) + identity"));
                 StencilParams& p = s.stn;
-                REL(s, p, in, B_ARENA, U.actT.off);
+                REL(s, p, in, B_ARENA, fuse_top ? U.rawT.off : U.actT.off);
                 REL(s, p, w, B_PARAMS, B.poff(P + ".1.conv.unit0.conv.weight") * sizeof(float));
                 REL(s, p, bias, B_PARAMS, B.poff(P + ".1.conv.unit0.conv.bias") * sizeof(float));
-                REL(s, p, addend, B_ARENA, U.actT.off);
+                if (fuse_top) {
+                    REL(s, p, nrm_stats, B_ARENA, U.statsT);
+                    REL(s, p, nrm_alpha, B_PARAMS, B.poff(P + ".0.adn.A.weight") * sizeof(float));
+                    p.nrm_eps = 1e-5f; p.nrm_layer = (unsigned)U.lidT;
+                    if (train) REL(s, p, act_out, B_ARENA, U.actT.off);
+                } else {
+                    REL(s, p, addend, B_ARENA, U.actT.off);
+                }
                 REL(s, p, out, B_LOGITS, 0);
                 p.flip = 0; p.ndim = nd; p.nb = nb;
                 for (int d = 0; d < 3; ++d) p.d[d] = u.rd[0][d];
                 s.kernel = "stencil_kernel";
-                s.work = (double)nb * u.rp[0] * 4.0 * 2.0;
+                s.work = (double)nb * u.rp[0] * 4.0 * (fuse_top && train ? 3.0 : 2.0);
                 u.flops_fwd += 2.0 * nb * u.rp[0] * KK;
             }
         }
@@ -997,7 +1012,15 @@ int run_step(mi_unet& u, Step& s, char* const* bases, int training, uint64_t see
         case K_C1_FWD: return launch_c1_s2_fwd(s.dtype, resolve(s, s.c1, bases), st);
         case K_C1_T: return launch_c1_s2_T(s.dtype, resolve(s, s.c1, bases), st);
         case K_C1_WGRAD: return launch_c1_s2_wgrad(s.dtype, resolve(s, s.c1, bases), st);
-        case K_STENCIL: return launch_stencil(resolve(s, s.stn, bases), st);
+        case K_STENCIL: {
+            StencilParams p = resolve(s, s.stn, bases);
+            if (p.nrm_stats) {
+                NormParams d; memset(&d, 0, sizeof(d));
+                norm_set_dropout(d, training ? u.cfg.dropout : 0.f);
+                p.nrm_seed = seed; p.nrm_thresh = d.drop_thresh; p.nrm_scale = d.drop_scale;
+            }
+            return launch_stencil(p, st);
+        }
         case K_STENCIL_WGRAD: return launch_stencil_wgrad(resolve(s, s.stn, bases), st);
         case K_ADD: {
             AddArgs a = resolve(s, s.add, bases);

@@ -137,6 +137,13 @@ struct StencilParams {
     int d[3];
     float* partial; float* partial_bias;    // [slab][KK], [slab]
     int nsplit;
+    // 2-D strip kernel, forward: `in` is a RAW one-channel convolution output; instance norm (statistics nrm_stats,
+    // [nb][NSLOT][2] fp64 sums over the image), dropout and PReLU are applied as the rows are loaded (pixels outside
+    // the image stay zero), the activated values of the thread's own pixels go to act_out (nullptr: nobody reads
+    // them) and serve as the identity addend.
+    const double* nrm_stats; const float* nrm_alpha; float nrm_eps;
+    unsigned long long nrm_seed; unsigned nrm_layer, nrm_thresh; float nrm_scale;
+    float* act_out;
 };
 
 #ifdef __cplusplus
@@ -168,6 +175,7 @@ int launch_c1_s2_fwd(int dtype, const C1Params& p, hipStream_t st);
 int launch_c1_s2_T(int dtype, const C1Params& p, hipStream_t st);
 int launch_c1_s2_wgrad(int dtype, const C1Params& p, hipStream_t st);
 int launch_stencil(const StencilParams& p, hipStream_t st);
+bool stencil_norm_on_load_ok(const StencilParams& p);   // small.hip: the 2-D strip kernel serves p (it can normalise on load)
 int launch_stencil_wgrad(const StencilParams& p, hipStream_t st);
 void igemm_config(int dtype, const IgemmParams& p, int* cps, int* nfrag);
 size_t igemm_lds_bytes(int dtype, const IgemmParams& p);

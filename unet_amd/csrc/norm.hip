@@ -341,20 +341,6 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const NormParams p)
 
 // ---- one-channel fp32 planar variants (top of the decoder) ------------------------
 // tensors are [nb][npix] fp32; four consecutive pixels per lane.
-__device__ __forceinline__ void c1_moments(const double* stats, int img, int npix, float eps, float& mean, float& rstd) {
-    double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-    for (int sl = 0; sl < MI_NSLOT; ++sl) {
-        s1 += stats[((size_t)img * MI_NSLOT + sl) * 2];
-        s2 += stats[((size_t)img * MI_NSLOT + sl) * 2 + 1];
-    }
-    const double m = s1 / (double)npix;
-    double var = s2 / (double)npix - m * m;
-    var = var > 0.0 ? var : 0.0;
-    mean = (float)m;
-    rstd = (float)(1.0 / sqrt(var + (double)eps));
-}
-
 // W = 4: four consecutive pixels per lane as one 16-byte access (npix a multiple of 4; they are exactly one
 // dropout group); W = 1: any npix.
 template <int W> struct PlanarVec;

@@ -726,6 +726,10 @@ __global__ __launch_bounds__(256) void stencil_kernel(const StencilParams p) {
 // requested before the first use (one 16-byte load plus the two neighbours per row), so each input row is
 // fetched (ST_R + 2) / ST_R times instead of three times and a thread has its whole working set in flight.
 constexpr int ST_R = 8;
+// NRM: the input is a raw one-channel convolution output that is normalised, dropped and activated as it is loaded
+// (same arithmetic as norm1_fwd_kernel: a 16-byte group of four pixels is one dropout group; the two halo pixels of
+// a row belong to the neighbouring groups); the thread's own pixels are the identity addend and go to act_out.
+template <bool NRM>
 __global__ __launch_bounds__(256) void stencil2d_strip_kernel(const StencilParams p) {
     const int H = p.d[1], W = p.d[2];
     const int qrow = W >> 2;
@@ -740,6 +744,21 @@ __global__ __launch_bounds__(256) void stencil2d_strip_kernel(const StencilParam
 #pragma unroll
     for (int k = 0; k < 9; ++k) w[k] = p.w[p.flip ? 8 - k : k];
     const float b = p.bias ? p.bias[0] : 0.f;
+    float mean = 0.f, rstd = 1.f, alpha = 0.f, scale = 1.f;
+    DropKeys dk = {0u, 0u, 0u, 0u};
+    bool drop = false;
+    if (NRM) {
+        c1_moments(p.nrm_stats, (int)blockIdx.y, H * W, p.nrm_eps, mean, rstd);
+        alpha = *p.nrm_alpha;
+        dk = dropout_keys(p.nrm_seed, p.nrm_layer, blockIdx.y, p.nrm_thresh);
+        scale = p.nrm_scale;
+        drop = p.nrm_thresh != 0;
+    }
+    auto activate = [&](float x, bool keep) {
+        float d = (x - mean) * rstd;
+        if (drop) d = keep ? d * scale : 0.f;
+        return d > 0.f ? d : alpha * d;
+    };
     float v[ST_R + 2][6];
 #pragma unroll
     for (int r = 0; r < ST_R + 2; ++r) {
@@ -755,8 +774,33 @@ __global__ __launch_bounds__(256) void stencil2d_strip_kernel(const StencilParam
             for (int j = 0; j < 6; ++j) v[r][j] = 0.f;
         }
     }
+    if (NRM) {
+#pragma unroll
+        for (int r = 0; r < ST_R + 2; ++r) {
+            const int yy = y0 - 1 + r;
+            if ((unsigned)yy < (unsigned)H) {
+                const unsigned gc = (unsigned)(yy * W + x0) >> 2;        // dropout group of the four centre pixels
+                bool kc[4] = {true, true, true, true}, kl[4] = {true, true, true, true}, kr[4] = {true, true, true, true};
+                if (drop) {
+                    dropout_keep4(dk, gc, kc);
+                    if (x0 > 0) dropout_keep4(dk, gc - 1u, kl);
+                    if (x0 + 4 < W) dropout_keep4(dk, gc + 1u, kr);
+                }
+                if (x0 > 0) v[r][0] = activate(v[r][0], kl[3]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[r][1 + j] = activate(v[r][1 + j], kc[j]);
+                if (x0 + 4 < W) v[r][5] = activate(v[r][5], kr[0]);
+            }
+        }
+        if (p.act_out) {
+#pragma unroll
+            for (int r = 0; r < ST_R; ++r)
+                if (y0 + r < H)
+                    *reinterpret_cast<float4*>(p.act_out + ibase + (size_t)(y0 + r) * W + x0) = make_float4(v[r + 1][1], v[r + 1][2], v[r + 1][3], v[r + 1][4]);
+        }
+    }
     float4 add[ST_R];
-    if (p.addend) {
+    if (!NRM && p.addend) {
 #pragma unroll
         for (int r = 0; r < ST_R; ++r)
             if (y0 + r < H) add[r] = *reinterpret_cast<const float4*>(p.addend + ibase + (size_t)(y0 + r) * W + x0);
@@ -771,7 +815,8 @@ __global__ __launch_bounds__(256) void stencil2d_strip_kernel(const StencilParam
             for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[j] += w[ky * 3 + kx] * v[r + ky][j + kx];
-        if (p.addend) { acc[0] += add[r].x; acc[1] += add[r].y; acc[2] += add[r].z; acc[3] += add[r].w; }
+        if (NRM) { acc[0] += v[r + 1][1]; acc[1] += v[r + 1][2]; acc[2] += v[r + 1][3]; acc[3] += v[r + 1][4]; }
+        else if (p.addend) { acc[0] += add[r].x; acc[1] += add[r].y; acc[2] += add[r].z; acc[3] += add[r].w; }
         *reinterpret_cast<float4*>(p.out + ibase + (size_t)(y0 + r) * W + x0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
 }
@@ -972,14 +1017,21 @@ int launch_c1_s2_wgrad(int dtype, const C1Params& p, hipStream_t st) {
     return check_launch("c1_s2_wgrad");
 }
 
+// the 2-D strip kernel serves p: whole 16-byte groups per row and at least four strips of rows
+bool stencil_norm_on_load_ok(const StencilParams& p) {
+    return p.ndim == 2 && p.d[0] == 1 && p.d[2] % 4 == 0 && p.d[1] >= 4 * ST_R && (long long)p.d[1] * p.d[2] < (1ll << 31);
+}
+
 int launch_stencil(const StencilParams& p, hipStream_t st) {
     const long long npix = (long long)p.d[0] * p.d[1] * p.d[2];
+    MI_CHECK(!p.nrm_stats || stencil_norm_on_load_ok(p), "this stencil cannot normalise its input on load");
     if (p.d[2] % 4 == 0) {
         const unsigned gx = (unsigned)((npix / 4 + 255) / 256);
         if (p.ndim == 3) hipLaunchKernelGGL(stencil_kernel<3>, dim3(gx, p.nb), dim3(256), 0, st, p);
         else if (p.d[1] >= 4 * ST_R) {
             const int threads = (p.d[2] >> 2) * ((p.d[1] + ST_R - 1) / ST_R);
-            hipLaunchKernelGGL(stencil2d_strip_kernel, dim3((threads + 255) / 256, p.nb), dim3(256), 0, st, p);
+            if (p.nrm_stats) hipLaunchKernelGGL(stencil2d_strip_kernel<true>, dim3((threads + 255) / 256, p.nb), dim3(256), 0, st, p);
+            else hipLaunchKernelGGL(stencil2d_strip_kernel<false>, dim3((threads + 255) / 256, p.nb), dim3(256), 0, st, p);
         } else hipLaunchKernelGGL(stencil_kernel<1>, dim3(gx, p.nb), dim3(256), 0, st, p);
     } else {
         hipLaunchKernelGGL(stencil_scalar_kernel, dim3((unsigned)((npix + 255) / 256), p.nb), dim3(256), 0, st, p);
