@@ -433,6 +433,18 @@ def main():
         conv_s = sum(r["ms"] for r in conv.values()) / 1e3
         conv_f = sum(r["flops"] for r in conv.values())
         out["mfma_util"] = round(conv_f / conv_s / MFMA_BF16_PEAK, 4) if conv_s else None
+        # the same over the launches whose arithmetic intensity lies above the ridge of the roofline (FLOP per
+        # algorithmic byte > MFMA peak / HBM peak): the layers the matrix cores, not the memory, can bound
+        above = [st for bw in (False, True) for st in plan.steps(bw)
+                 if st["work_is_flops"] and st["launches"] and st["bytes"] > 0 and st["work"] / st["bytes"] > RIDGE]
+        if above and args.dtype == "bf16":
+            a_ms = sum(st["total_ms"] for st in above)
+            a_fl = sum(st["work"] * st["launches"] for st in above)
+            out["mfma_bound_layers"] = {"launches_per_step": round(sum(st["launches"] for st in above) / nprof, 1),
+                                        "tflops": round(a_fl / (a_ms / 1e3) / 1e12, 1),
+                                        "frac_of_peak": round(a_fl / (a_ms / 1e3) / MFMA_BF16_PEAK, 4),
+                                        "share_of_kernel_time": round(a_ms / tot_ms, 3),
+                                        "ridge_flop_per_byte": round(RIDGE, 1)}
         dom_name, dom = max(rows.items(), key=lambda kv: kv[1]["ms"])
         sec = dom["ms"] / 1e3
         ai = dom["flops"] / max(dom["bytes"], 1.0)
