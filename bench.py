@@ -390,7 +390,7 @@ def main():
     plan = model._plan_for(x, True)
     flops_step = plan.flops(False) + plan.flops(True)
     out = {
-        "metric": "train slices/sec (whole node) 2D U-Net 512x512 bf16" if args.dims == 2 else "train patches/sec (whole node) 3D U-Net",
+        "metric": f"train slices/sec (whole node) 2D U-Net {args.size}x{args.size} {args.dtype}" if args.dims == 2 else "train patches/sec (whole node) 3D U-Net",
         "value": round(value, 2), "unit": "slices/s" if args.dims == 2 else "patches/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
