@@ -484,10 +484,9 @@ bool build(mi_unet& u) {
         // Weight packing runs beside the first layers in two launches: the weights of the first encoder levels (few),
         // which the first MFMA convolution waits for, and everything else (the deep levels hold nearly all
         // parameters), which the first deep layer joins.  The split point is patched in after the build.
-        Step& p = B.push(u.fwd, K_PACK, "pack weights (first levels)");
-        p.kernel = dt ? "pack_kernel<BF16>" : "pack_kernel<F32>";
-        Step& q = B.push(u.fwd, K_PACK, "pack weights");
-        q.kernel = p.kernel;
+        const char* pack_name = dt ? "pack_kernel<BF16>" : "pack_kernel<F32>";
+        B.push(u.fwd, K_PACK, "pack weights (first levels)").kernel = pack_name;      // push() may move earlier steps
+        B.push(u.fwd, K_PACK, "pack weights").kernel = pack_name;
     }
     constexpr int PACK_CUT_LEVEL = 3;              // encoder levels below this one belong to the first launch
     int packs_first = -1; size_t first_rest_step = 0;
