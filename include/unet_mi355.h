@@ -56,7 +56,7 @@ typedef struct mi_param_info {
     int32_t shape[5];
     int64_t numel;
     int64_t offset;            /* element offset inside the flat fp32 parameter / gradient buffers */
-    int32_t bucket;            /* gradient bucket: 0 decoder, 1 bottom, 2 encoder (backward completion order) */
+    int32_t bucket;            /* gradient bucket in backward completion order: 0 decoder, 1 bottom, 2 encoder levels >= 1, 3 encoder level 0 */
 } mi_param_info;
 
 int mi_unet_create(const mi_unet_cfg* cfg, mi_unet** out);
@@ -65,6 +65,8 @@ int mi_unet_num_params(const mi_unet* u);                     /* parameter tenso
 int mi_unet_param_info(const mi_unet* u, int i, mi_param_info* info);   /* i in state_dict order */
 int64_t mi_unet_param_floats(const mi_unet* u);               /* length of the flat buffers */
 size_t mi_unet_workspace_bytes(const mi_unet* u);
+#define MI_NUM_BUCKETS 4
+int mi_unet_num_buckets(const mi_unet* u);                    /* MI_NUM_BUCKETS; a bucket may be empty (count 0) */
 int mi_unet_bucket_range(const mi_unet* u, int bucket, int64_t* offset, int64_t* count);
 double mi_unet_flops(const mi_unet* u, int backward);          /* 2*MAC of the convolutions of one call */
 int mi_unet_num_steps(const mi_unet* u, int backward);         /* kernel launches per call (host logic check) */
@@ -75,7 +77,8 @@ int mi_unet_forward(mi_unet* u, const float* params, const float* x, float* logi
 /* grads (flat fp32, same layout as params) of the forward that last used `workspace`.
  * `x` is the forward's input (the first layer's weight gradient reads it);
  * `training` and `seed` must repeat the forward's values (the dropout mask is recomputed, not stored).
- * bucket < 0: whole backward; otherwise buckets must be run in order 0,1,2. */
+ * bucket < 0: whole backward; otherwise buckets must be run in order 0 .. MI_NUM_BUCKETS-1: when the call for
+ * bucket i returns, everything that writes bucket i's range of `grads` has been enqueued on `stream`. */
 int mi_unet_backward(mi_unet* u, const float* params, const float* x, const float* dlogits, float* grads,
                      void* workspace, int training, uint64_t seed, int bucket, void* stream);
 

@@ -49,3 +49,20 @@ def test_older_kernels_agree_with_the_default_selection(tmp_path, baseline, swit
         d = got["grads"][k]
         ok = rel_l2(d, g) < 0.15 or float((d - g).abs().max()) < 5e-3 * scale
         assert ok, (k, rel_l2(d, g), float((d - g).abs().max()), scale)
+
+
+KERNEL_SWITCHES = [s for s in SWITCHES if s not in ("MI_NO_SIDE_STREAM", "MI_NO_NORM_ON_LOAD")]
+
+
+def test_older_kernels_meet_the_operator_bounds_against_the_oracle(dev):
+    """The tight check of the kernels behind the switches: with every newer kernel family switched off at once, the
+    operator-level parity tests (each convolution form, forward / data gradient / weight gradient, against torch's CPU
+    convolution: 2e-5 in fp32, bf16 products exact) run again in a child process on the older kernels.  The default
+    selection passes the same tests in this process, so both selections are held to the oracle layer by layer."""
+    env = {k: v for k, v in os.environ.items() if not k.startswith("MI_NO_")}
+    for s in KERNEL_SWITCHES:
+        env[s] = "1"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(HERE, "test_ops_gpu.py"), "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "test_conv_forward_dgrad_wgrad or test_conv_exact_integer_data"], env=env, capture_output=True, text=True, timeout=170, cwd=os.path.dirname(HERE))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout

@@ -45,8 +45,12 @@ def test_param_table_matches_oracle_state_dict(dims, channels):
     assert all(a % 4 == 0 for a, _ in spans)
     assert all(spans[i][1] <= spans[i + 1][0] for i in range(len(spans) - 1))
     assert spans[-1][1] <= m._nfloats
-    (o0, c0), (o1, c1), (o2, c2) = m.gradient_buckets()
-    assert o0 == 0 and o1 == c0 and o2 == c0 + c1 and c0 + c1 + c2 == m._nfloats
+    buckets = m.gradient_buckets()
+    assert len(buckets) == 4 and buckets[0][0] == 0 and sum(c for _, c in buckets) == m._nfloats
+    assert all(buckets[i + 1][0] == buckets[i][0] + buckets[i][1] for i in range(3))
+    # bucket 3 = the first encoder level (the last gradients of the backward pass), bucket 2 = the deeper encoder levels
+    assert {b for name, _, _, _, b in table if name.startswith("model.0.")} == {3}
+    assert (buckets[2][1] == 0) == (len(channels) == 2)
     for name, _, n, off, b in table:
         lo, cnt = m.gradient_buckets()[b]
         assert lo <= off and off + n <= lo + cnt

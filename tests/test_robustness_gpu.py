@@ -132,3 +132,38 @@ def test_optimizer_state_round_trips_in_torch_format(dev):
     o3.step()
     for r, p in zip(ref, m1.parameters()):
         assert float((r.detach() - p.detach()).abs().max()) < 1e-6
+
+
+def test_optimizer_state_loaded_on_the_cpu_follows_the_model_to_the_gpu(dev):
+    """A checkpoint loaded while the model still lives on the CPU must keep its moments when the model moves:
+    one more step has to land where an uninterrupted run lands, bit for bit."""
+    def make(device):
+        torch.manual_seed(6)
+        m = unet_amd.UNet(2, 1, 1, (16, 32), (2,), num_res_units=2, compute_dtype=torch.float32).to(device).train()
+        return m, unet_amd.AdamW(m.parameters(), lr=2e-3, weight_decay=1e-2, model=m)
+
+    loss = unet_amd.DiceCELoss(sigmoid=True)
+    x = torch.rand(2, 1, 32, 32, device=dev)
+    t = disks(2, (32, 32), 8).to(dev)
+
+    def step(m, opt):
+        opt.zero_grad()
+        loss(m(x), t).backward()
+        opt.step()
+
+    m1, o1 = make(dev)
+    for _ in range(3):
+        step(m1, o1)
+    sd_model = {k: v.detach().cpu().clone() for k, v in m1.state_dict().items()}
+    sd_opt = o1.state_dict()
+    sd_opt["state"] = {i: {k: v.cpu() for k, v in s.items()} for i, s in sd_opt["state"].items()}
+    step(m1, o1)
+    m2, o2 = make("cpu")
+    m2.load_state_dict(sd_model)
+    o2.load_state_dict(sd_opt)
+    assert o2._m is not None and not o2._m.is_cuda and float(o2._m.abs().sum()) > 0
+    m2.to(dev)
+    step(m2, o2)
+    torch.cuda.synchronize()
+    assert o2._m.is_cuda and o2._step == 4
+    assert torch.equal(m1.flat_parameters(), m2.flat_parameters())

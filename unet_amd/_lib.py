@@ -71,6 +71,7 @@ PROTOTYPES = {
     "mi_unet_param_info": (C.c_int, [_P, C.c_int, C.POINTER(MiParamInfo)]),
     "mi_unet_param_floats": (C.c_int64, [_P]),
     "mi_unet_workspace_bytes": (C.c_size_t, [_P]),
+    "mi_unet_num_buckets": (C.c_int, [_P]),
     "mi_unet_bucket_range": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "mi_unet_flops": (C.c_double, [_P, C.c_int]),
     "mi_unet_num_steps": (C.c_int, [_P, C.c_int]),

@@ -1177,6 +1177,12 @@ static int conv2d_dma_kind(int dtype, const IgemmParams& p) {
     const int kce = 64 / (dtype ? 2 : 4);
     if (p.id[0] != 1 || p.tlog[0] != 0 || p.tlog[1] != 4 || p.tlog[2] != 4 || p.pd[0] != 1) return 0;
     if (p.ksplit > 1) return 0;
+    {
+        // per-lane DMA source offsets are 32-bit byte offsets from the patch origin: (row * W + column) * pixel pitch over
+        // the rows of one patch (stride-2 forms step two pixels) must stay below 2^31 for the widest source
+        const long long pitch = p.in0_c < p.K && p.in1_pitch > p.in0_pitch ? p.in1_pitch : p.in0_pitch;
+        if ((long long)(p.pd[1] + 2) * p.id[2] * pitch * (dtype ? 2 : 4) >= (1ll << 31)) return 0;
+    }
     if (dtype && p.K == 16 && p.in0_c >= 16 && p.N % 16 == 0 && p.sa == 1 && p.so == 1 && p.nphase == 1 && p.phase_start[1] == 9 &&
         p.pd[1] == 18 && p.pd[2] == 18 && p.id[1] < 32768 && p.id[2] < 32768) {
         // 16 bf16 contraction channels from one source, 3 x 3 taps in patch order

@@ -104,7 +104,7 @@ struct mi_unet {
     std::vector<ParamRec> params;
     std::map<std::string, int> pindex;
     long long nfloats = 0;
-    long long bucket_off[3], bucket_cnt[3];
+    long long bucket_off[MI_NUM_BUCKETS], bucket_cnt[MI_NUM_BUCKETS];
     std::vector<Step> fwd, bwd;
     size_t arena = 0;
     // descriptor tables (pointer fields hold offsets until resolved)
@@ -378,7 +378,7 @@ void enum_params(mi_unet& u) {
             const int cin = l == 0 ? u.cfg.in_channels : c[l - 1];
             const int cout = c[l];
             // down residual unit at P.0 (stride 2)
-            res_unit(u, P + ".0", cin, cout, 3, R, false, 2, add, wshape);
+            res_unit(u, P + ".0", cin, cout, 3, R, false, l == 0 ? 3 : 2, add, wshape);
             if (l < L - 2) block(u, P + ".1.submodule", l + 1, add, wshape);
             else res_unit(u, P + ".1.submodule", c[L - 2], c[L - 1], (c[L - 2] != c[L - 1]) ? 1 : 0, R, false, 1, add, wshape);
             // up layer at P.2
@@ -411,7 +411,7 @@ void enum_params(mi_unet& u) {
     (void)L; (void)R; (void)c;
     // offsets in backward-completion (bucket) order, 16-byte aligned
     long long off = 0;
-    for (int b = 0; b < 3; ++b) {
+    for (int b = 0; b < MI_NUM_BUCKETS; ++b) {
         u.bucket_off[b] = off;
         // within the decoder bucket the top layer finishes first; order by level for buckets 0 and 2
         std::vector<int> idx;
@@ -914,10 +914,12 @@ bool build(mi_unet& u) {
                 }
             }
             // everything but level 0 is reduced while level 0 is still being differentiated, so that the reduction left
-            // behind the last weight gradient (nothing else runs then) covers level 0 only
-            if (l == 1 && !getenv("MI_NO_SPLIT_REDUCE")) B.push_reduce_step("reduce gradients: encoder bucket, levels 1 and deeper");
+            // behind the last weight gradient (nothing else runs then) covers level 0 only; level 0 is a bucket of its
+            // own, so a data-parallel caller's all-reduce of the deeper encoder levels runs beside level 0's backward
+            if (l == 1) { B.push_reduce_step("reduce gradients: encoder bucket, levels 1 and deeper"); B.cur_bucket = 3; }
         }
-        B.push_reduce_step("reduce gradients: encoder bucket");
+        B.cur_bucket = 3;
+        B.push_reduce_step("reduce gradients: encoder bucket, level 0");
     }
 
     // ---- descriptor tables: the ranges of descriptors each table step launches ----
@@ -1179,6 +1181,7 @@ void mi_unet_destroy(mi_unet* u) {
 }
 
 int mi_unet_num_params(const mi_unet* u) { return (int)u->params.size(); }
+int mi_unet_num_buckets(const mi_unet*) { return MI_NUM_BUCKETS; }
 
 int mi_unet_param_info(const mi_unet* u, int i, mi_param_info* info) {
     MI_CHECK(u && info && i >= 0 && i < (int)u->params.size(), "bad index");
@@ -1195,7 +1198,7 @@ int64_t mi_unet_param_floats(const mi_unet* u) { return u->nfloats; }
 size_t mi_unet_workspace_bytes(const mi_unet* u) { return u->arena; }
 
 int mi_unet_bucket_range(const mi_unet* u, int bucket, int64_t* offset, int64_t* count) {
-    MI_CHECK(u && bucket >= 0 && bucket < 3, "bad bucket");
+    MI_CHECK(u && offset && count && bucket >= 0 && bucket < MI_NUM_BUCKETS, "bad bucket");
     *offset = u->bucket_off[bucket]; *count = u->bucket_cnt[bucket];
     return 0;
 }
@@ -1216,7 +1219,7 @@ int mi_unet_backward(mi_unet* u, const float* params, const float* x, const floa
                      int training, uint64_t seed, int bucket, void* stream) {
     MI_CHECK(u && params && x && dlogits && grads && workspace, "null argument");
     MI_CHECK(u->cfg.with_backward, "plan was created without a backward pass");
-    MI_CHECK(bucket < 3, "bucket must be < 3");
+    MI_CHECK(bucket < MI_NUM_BUCKETS, "bucket must be < MI_NUM_BUCKETS");
     char* bases[B_NBASE] = {nullptr};
     bases[B_ARENA] = (char*)workspace; bases[B_PARAMS] = (char*)params; bases[B_GRADS] = (char*)grads;
     bases[B_DLOGITS] = (char*)dlogits; bases[B_XIN] = (char*)x;

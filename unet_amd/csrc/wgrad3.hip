@@ -761,11 +761,9 @@ static int launch_wgrad_thin(int dtype, const WgradParams& p, int ff, int sf, in
     const dim3 grid(p.nsplit, p.F / (16 * ff), p.S / (16 * ff));
     constexpr int R = 3;
     const size_t lds = (size_t)R * (8 + 12) * 1024;
-    static bool done = false;
-    if (!done) {
+    {   // per (kernel, device) inside mi_func_set_lds: a second GPU of the process gets the attribute too
         hipError_t e = mi_func_set_lds(reinterpret_cast<const void*>(wgrad_thin_kernel<2, R>), (int)lds);
         if (e != hipSuccess) { mi_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return -2; }
-        done = true;
     }
     hipLaunchKernelGGL((wgrad_thin_kernel<2, R>), grid, dim3(256), lds, st, p);
     hipError_t e = hipGetLastError();
@@ -785,11 +783,9 @@ int launch_wgrad_thick(int dtype, const WgradParams& p, int ff, int sf, int wf, 
     if (p.ss == 2) {
         const size_t lds2 = 2 * 16 * 1024 + 4 * (sf == 2 ? 10 : 5) * 1024;
         auto kern2 = sf == 2 ? wgrad_thick_s2_kernel<2> : wgrad_thick_s2_kernel<1>;
-        static bool attr2[2] = {false, false};
-        if (!attr2[sf - 1]) {
+        {
             hipError_t e = mi_func_set_lds(reinterpret_cast<const void*>(kern2), (int)lds2);
             if (e != hipSuccess) { mi_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return -2; }
-            attr2[sf - 1] = true;
         }
         dim3 grid2(p.nsplit, p.F / 64, p.S / (16 * sf));
         hipLaunchKernelGGL(kern2, grid2, dim3(256), lds2, st, p);
@@ -798,11 +794,9 @@ int launch_wgrad_thick(int dtype, const WgradParams& p, int ff, int sf, int wf, 
         return 0;
     }
     constexpr size_t lds = 2 * (16 + 23) * 1024;
-    static bool attr_done = false;
-    if (!attr_done) {
+    {
         hipError_t e = mi_func_set_lds(reinterpret_cast<const void*>(wgrad_thick_kernel), (int)lds);
         if (e != hipSuccess) { mi_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return -2; }
-        attr_done = true;
     }
     dim3 grid(p.nsplit, p.F / 64, p.S / 64);
     hipLaunchKernelGGL(wgrad_thick_kernel, grid, dim3(256), lds, st, p);

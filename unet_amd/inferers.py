@@ -61,8 +61,9 @@ def _windows_per_call(predictor, sw_batch_size: int, total: int, window_elems: i
     MONAI's ``sw_batch_size`` only bounds memory.  For this package's U-Net in eval mode every window is an
     independent sample (instance norm, dropout off), so a larger group gives the same numbers in fewer, fuller
     launches.  The group size is then a power of two (or the maximum), and a short last group is padded with
-    zero windows whose outputs are dropped: whatever the image size, the U-Net sees only a handful of batch
-    sizes and builds only that many engine plans.  Any other predictor gets exactly the group size it was asked
+    zero windows, whose outputs are dropped, up to the next power of two (not to the full group: a tail of one
+    window costs one window): whatever the image size, the U-Net sees only the batch sizes 1, 2, 4 ... and the
+    maximum, and builds at most that many engine plans (``UNet.MAX_PLANS`` covers the set).  Any other predictor gets exactly the group size it was asked
     for and an unpadded tail (``UNET_AMD_SW_EXACT=1`` forces that for the U-Net too)."""
     import os
 
@@ -136,8 +137,8 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size, sw_batch_size: int,
     group, pad_tail = _windows_per_call(predictor, sw_batch_size, total, rpix)
     for g in range(0, total, group):
         n = min(group, total - g)
-        if n < group and pad_tail:
-            wins = torch.zeros((group, 1) + tuple(roi), dtype=torch.float32, device=dev)
+        if n < group and pad_tail and n & (n - 1):
+            wins = torch.zeros((min(group, 1 << n.bit_length()), 1) + tuple(roi), dtype=torch.float32, device=dev)
         else:
             wins = torch.empty((n, 1) + tuple(roi), dtype=torch.float32, device=dev)
         _lib.check(lib.mi_sw_gather(x.data_ptr(), wins.data_ptr(), starts_dev.data_ptr(), nwin, g, n, nb, img3, roi3,

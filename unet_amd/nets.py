@@ -146,7 +146,7 @@ class _Plan:
 
     def bucket_ranges(self):
         out = []
-        for b in range(3):
+        for b in range(self.lib.mi_unet_num_buckets(self.h)):
             o, c = C.c_int64(), C.c_int64()
             _lib.check(self.lib.mi_unet_bucket_range(self.h, b, C.byref(o), C.byref(c)))
             out.append((o.value, c.value))
@@ -395,11 +395,13 @@ class UNet(nn.Module):
         return self._ensure_flat(dev)
 
     def gradient_buckets(self):
-        """[(offset, count)] of the three gradient buckets in backward-completion order."""
+        """[(offset, count)] of the gradient buckets in backward-completion order (decoder, bottom, encoder levels
+        1 and deeper, encoder level 0); a bucket may be empty."""
         self._layout()
         return list(self._buckets)
 
-    MAX_PLANS = 8     # engine plans (one per batch size / spatial size / direction set) kept per model
+    MAX_PLANS = 12    # engine plans (one per batch size / spatial size / direction set) kept per model: sliding-window
+                      # inference alone asks for the batch sizes 1, 2, 4 ... 256 and 288 (ten plans)
 
     def _plan_for(self, x, with_backward):
         key = (x.shape[0], tuple(x.shape[2:]), _DT[self.compute_dtype], bool(with_backward))

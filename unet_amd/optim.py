@@ -126,9 +126,13 @@ class AdamW(torch.optim.Optimizer):
         if not flat.is_cuda:
             raise RuntimeError("unet_amd.AdamW runs on an AMD GPU only (no CPU or eager fallback)")
         g = flat_grad if flat_grad is not None else self._flat_grad(model, flat)
-        if self._m is None or self._m.device != flat.device:
+        if self._m is None:
             self._m = torch.zeros_like(flat)
             self._v = torch.zeros_like(flat)
+        elif self._m.device != flat.device:
+            # moments loaded (or accumulated) while the model lived elsewhere follow it; they are never reset
+            self._m = self._m.to(flat.device)
+            self._v = self._v.to(flat.device)
         grp = self.param_groups[0]
         self._step += 1
         lib = _lib.load()

@@ -2,8 +2,8 @@
 
 One process per GPU, ``torch.distributed`` (backend "nccl" = RCCL over xGMI on ROCm; "gloo" on CPU for
 tests).  Training: the batch is sharded, every rank holds a replica, gradients live in ONE flat
-fp32 buffer that the engine fills in three buckets in backward-completion order (decoder, bottom,
-encoder); each bucket is all-reduced on a side stream as soon as its part of the backward has been
+fp32 buffer that the engine fills in four buckets in backward-completion order (decoder, bottom,
+encoder levels 1 and deeper, encoder level 0); each bucket is all-reduced on a side stream as soon as its part of the backward has been
 enqueued, overlapping the rest of the backward.  Instance norm needs no cross-rank statistics.
 Inference: independent slices are sharded; the only exchange is the final sum of Dice partials.
 """

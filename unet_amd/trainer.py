@@ -103,14 +103,14 @@ class Trainer:
                                            b["sums"].data_ptr(), 0, 1.0, b["dlogits"].data_ptr(), st),
                    "mi_dice_ce_loss_bwd")
         if self._reducer is not None and self.overlap:
-            for bucket in range(3):
+            for bucket in range(len(self._reducer.buckets)):
                 plan.backward(flat, x, b["dlogits"], self._grad, b["ws"], True, seed, bucket)
                 self._reducer.launch(bucket)
             self._reducer.wait()
         else:
             plan.backward(flat, x, b["dlogits"], self._grad, b["ws"], True, seed, -1)
             if self._reducer is not None:
-                for bucket in range(3):
+                for bucket in range(len(self._reducer.buckets)):
                     self._reducer.launch(bucket)
                 self._reducer.wait()
         self.opt.step(flat_grad=self._grad, grad_scale=1.0 / self.world, flat=flat)
