@@ -82,6 +82,37 @@ int mi_unet_forward(mi_unet* u, const float* params, const float* x, float* logi
 int mi_unet_backward(mi_unet* u, const float* params, const float* x, const float* dlogits, float* grads,
                      void* workspace, int training, uint64_t seed, int bucket, void* stream);
 
+/* One optimisation step in one call: the body of the reference's inner loop, reference/train.py:111-118
+ * (labels==2 -> 1 folded into the loss read, model(inputs), loss_function(outputs, labels), loss.backward(),
+ * optimizer.step()), enqueued on `stream` from C: forward in training mode, Dice(+CE) loss forward and backward, the
+ * whole backward pass and, when `do_adamw` is set, AdamW over the flat buffers.  Same kernels, same order and same
+ * results, bit for bit, as mi_unet_forward + mi_dice_ce_loss_fwd + mi_dice_ce_loss_bwd + mi_unet_backward(bucket -1) +
+ * mi_adamw_step with the same arguments; it exists because a step of a small batch is bound by the host when every
+ * part is a call of its own from Python.  Data-parallel callers that exchange gradient buckets between the parts of
+ * the backward pass keep using the separate entry points. */
+typedef struct mi_train_step_args {
+    float* params;             /* flat fp32 parameters (updated in place when do_adamw) */
+    const float* x;            /* input batch [nb][1][...] fp32 */
+    const void* target;        /* labels, same shape; dtype code below */
+    float* logits;             /* [nb][1][...] fp32, written */
+    float* dlogits;            /* same shape, scratch (gradient of the loss wrt the logits) */
+    double* loss_sums;         /* [nb][4] scratch */
+    float* loss;               /* [1], written */
+    float* loss_accum;         /* optional running sum of the step losses (may be NULL) */
+    float* grads;              /* flat fp32 gradients, written */
+    float* exp_avg;            /* AdamW moments (flat fp32; unused unless do_adamw) */
+    float* exp_avg_sq;
+    void* workspace;           /* mi_unet_workspace_bytes */
+    int32_t target_dtype;      /* 0 fp32, 1 uint8, 2 int64, 3 int32 */
+    int32_t fold2;             /* label value 2 counts as 1 (train.py:112-113) */
+    float smooth_nr, smooth_dr, lambda_dice, lambda_ce;
+    int32_t do_adamw;
+    float lr, beta1, beta2, eps, weight_decay, grad_scale;
+    int64_t step;              /* AdamW step count of this update (>= 1) */
+    uint64_t seed;             /* dropout seed of this step */
+} mi_train_step_args;
+int mi_unet_train_step(mi_unet* u, const mi_train_step_args* a, void* stream);
+
 /* Per-launch timing: when enabled every kernel launch of the engine is bracketed by HIP events on
  * its stream.  mi_unet_prof_collect() synchronises those events and adds the elapsed times to the
  * per-step accumulators read by mi_unet_step_info(). */

@@ -2,6 +2,7 @@
 array inside the library) against mi_dice_ce_loss_fwd with a caller buffer, through the C ABI: two calls in a
 row, the second on a smaller input, so that what the first call left in the shared array must not leak."""
 import ctypes as C
+import gc
 
 import pytest
 import torch
@@ -24,10 +25,17 @@ def _both(lib, fn, z, t, tcode, fold2, lambda_ce):
     acc = torch.full((1,), 10.0, device=dev)
     _lib.check(lib.mi_dice_ce_loss_fwd(z.data_ptr(), t.data_ptr(), tcode, fold2, nb, npix, 1e-5, 1e-5, 1.0, lambda_ce,
                                        sums.data_ptr(), ref.data_ptr(), 0, st), "mi_dice_ce_loss_fwd")
-    before = torch.cuda.memory_allocated(dev)
-    _lib.check(fn(z.data_ptr(), t.data_ptr(), tcode, fold2, nb, npix, 1e-5, 1e-5, 1.0, lambda_ce, got.data_ptr(),
-                  acc.data_ptr(), st), "mi_dice_ce_loss_fwd_noalloc")
-    assert torch.cuda.memory_allocated(dev) == before
+    # the allocator's count must not move across the call; the cycle collector is held off meanwhile (tensors of
+    # earlier tests that it frees at a moment of its own choosing would move the count without any allocation)
+    gc.collect()
+    gc.disable()
+    try:
+        before = torch.cuda.memory_allocated(dev)
+        _lib.check(fn(z.data_ptr(), t.data_ptr(), tcode, fold2, nb, npix, 1e-5, 1e-5, 1.0, lambda_ce, got.data_ptr(),
+                      acc.data_ptr(), st), "mi_dice_ce_loss_fwd_noalloc")
+        assert torch.cuda.memory_allocated(dev) == before
+    finally:
+        gc.enable()
     torch.cuda.synchronize()
     return float(ref), float(got), float(acc)
 

@@ -37,6 +37,18 @@ class MiStepInfo(C.Structure):
     ]
 
 
+class MiTrainStepArgs(C.Structure):
+    _fields_ = [
+        ("params", C.c_void_p), ("x", C.c_void_p), ("target", C.c_void_p), ("logits", C.c_void_p), ("dlogits", C.c_void_p),
+        ("loss_sums", C.c_void_p), ("loss", C.c_void_p), ("loss_accum", C.c_void_p), ("grads", C.c_void_p),
+        ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("workspace", C.c_void_p),
+        ("target_dtype", C.c_int32), ("fold2", C.c_int32), ("smooth_nr", C.c_float), ("smooth_dr", C.c_float),
+        ("lambda_dice", C.c_float), ("lambda_ce", C.c_float), ("do_adamw", C.c_int32), ("lr", C.c_float),
+        ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float),
+        ("grad_scale", C.c_float), ("step", C.c_int64), ("seed", C.c_uint64),
+    ]
+
+
 class MiNormInfo(C.Structure):
     _fields_ = [
         ("raw_offset", C.c_int64), ("pitch", C.c_int32), ("coff", C.c_int32), ("c", C.c_int32), ("dtype", C.c_int32),
@@ -77,6 +89,7 @@ PROTOTYPES = {
     "mi_unet_num_steps": (C.c_int, [_P, C.c_int]),
     "mi_unet_forward": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_uint64, _P]),
     "mi_unet_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_uint64, C.c_int, _P]),
+    "mi_unet_train_step": (C.c_int, [_P, C.POINTER(MiTrainStepArgs), _P]),
     "mi_unet_prof_enable": (C.c_int, [_P, C.c_int]),
     "mi_unet_prof_collect": (C.c_int, [_P]),
     "mi_unet_prof_reset": (C.c_int, [_P]),

@@ -1227,6 +1227,34 @@ int mi_unet_backward(mi_unet* u, const float* params, const float* x, const floa
     return run_list(*u, u->bwd, 1, bucket, bases, training, seed, st);
 }
 
+int mi_unet_train_step(mi_unet* u, const mi_train_step_args* a, void* stream) {
+    MI_CHECK(u && a, "null argument");
+    MI_CHECK(a->params && a->x && a->target && a->logits && a->dlogits && a->loss_sums && a->loss && a->grads && a->workspace,
+             "null buffer");
+    MI_CHECK(u->cfg.with_backward, "plan was created without a backward pass");
+    MI_CHECK(!a->do_adamw || (a->exp_avg && a->exp_avg_sq && a->step >= 1), "AdamW needs its moment buffers and a step count >= 1");
+    const long long npix = u->rp[0];
+    MI_CHECK(npix < 2147483647LL, "bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    char* bases[B_NBASE] = {nullptr};
+    bases[B_ARENA] = (char*)a->workspace; bases[B_PARAMS] = (char*)a->params; bases[B_XIN] = (char*)a->x;
+    bases[B_LOGITS] = (char*)a->logits;
+    if (int r = run_list(*u, u->fwd, 0, -1, bases, 1, a->seed, st)) return r;
+    LossParams p; memset(&p, 0, sizeof(p));
+    p.logits = a->logits; p.target = a->target; p.tdtype = a->target_dtype; p.fold2 = a->fold2; p.sums = a->loss_sums;
+    p.loss = a->loss; p.loss_accum = a->loss_accum; p.nb = u->nb; p.npix = (int)npix;
+    p.smooth_nr = a->smooth_nr; p.smooth_dr = a->smooth_dr; p.lambda_dice = a->lambda_dice; p.lambda_ce = a->lambda_ce;
+    if (int r = launch_loss_fwd(p, st)) return r;
+    p.dlogits = a->dlogits; p.gout = nullptr; p.gscale = 1.0f;
+    if (int r = launch_loss_bwd(p, st)) return r;
+    bases[B_LOGITS] = nullptr; bases[B_GRADS] = (char*)a->grads; bases[B_DLOGITS] = (char*)a->dlogits;
+    if (int r = run_list(*u, u->bwd, 1, -1, bases, 1, a->seed, st)) return r;
+    if (a->do_adamw)
+        return mi_adamw_step(a->params, a->grads, a->exp_avg, a->exp_avg_sq, u->nfloats, a->lr, a->beta1, a->beta2, a->eps,
+                             a->weight_decay, a->step, a->grad_scale, stream);
+    return 0;
+}
+
 // debug aid: arena offset of the tensor each step writes (-1 when it writes outside the arena)
 int64_t mi_unet_step_output_offset(const mi_unet* u, int backward, int i) {
     const std::vector<Step>& l = backward ? u->bwd : u->fwd;

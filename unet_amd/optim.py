@@ -111,6 +111,16 @@ class AdamW(torch.optim.Optimizer):
             raise ValueError("unet_amd.AdamW keeps one step counter: the loaded parameters disagree on it")
         self._m, self._v, self._step = m, v, steps.pop()
 
+    def _ensure_state(self, flat):
+        """Moment buffers laid out like ``flat`` on its device: created at zero on first use; moments loaded (or
+        accumulated) while the model lived elsewhere follow it and are never reset."""
+        if self._m is None:
+            self._m = torch.zeros_like(flat)
+            self._v = torch.zeros_like(flat)
+        elif self._m.device != flat.device:
+            self._m = self._m.to(flat.device)
+            self._v = self._v.to(flat.device)
+
     @torch.no_grad()
     def step(self, closure=None, *, flat_grad=None, grad_scale: float = 1.0, flat=None):
         loss = None
@@ -126,13 +136,7 @@ class AdamW(torch.optim.Optimizer):
         if not flat.is_cuda:
             raise RuntimeError("unet_amd.AdamW runs on an AMD GPU only (no CPU or eager fallback)")
         g = flat_grad if flat_grad is not None else self._flat_grad(model, flat)
-        if self._m is None:
-            self._m = torch.zeros_like(flat)
-            self._v = torch.zeros_like(flat)
-        elif self._m.device != flat.device:
-            # moments loaded (or accumulated) while the model lived elsewhere follow it; they are never reset
-            self._m = self._m.to(flat.device)
-            self._v = self._v.to(flat.device)
+        self._ensure_state(flat)
         grp = self.param_groups[0]
         self._step += 1
         lib = _lib.load()

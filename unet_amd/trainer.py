@@ -22,9 +22,12 @@ from .parallel import BucketedAllReduce
 
 class Trainer:
     def __init__(self, model: UNet, loss: DiceCELoss, optimizer: AdamW, *, group=None, overlap: bool = True,
-                 force_reducer: bool = False):
+                 force_reducer: bool = False, split_calls: bool = False):
         """``force_reducer``: run the bucketed all-reduce path even in a process group of one rank (it then
-        exercises the bucket-by-bucket backward, the communication stream and its events; the sums are unchanged)."""
+        exercises the bucket-by-bucket backward, the communication stream and its events; the sums are unchanged).
+        ``split_calls``: on a single device, enqueue the step as separate library calls (forward, loss, backward,
+        AdamW) instead of the one-call ``mi_unet_train_step``; the results are the same bit for bit."""
+        self.split_calls = split_calls
         self.model, self.loss, self.opt = model, loss, optimizer
         optimizer.bind(model)
         self.group = group
@@ -91,8 +94,27 @@ class Trainer:
         st = _lib.current_stream(dev)
         # every rank draws its own dropout masks
         seed = (model._next_seed() + 0x9E3779B97F4A7C15 * self.rank) & 0xFFFFFFFFFFFFFFFF
-        nb, npix = x.shape[0], x[0].numel()
         L = self.loss
+        if self._reducer is None and not self.split_calls:
+            # single device: the whole step is one call into the library (mi_unet_train_step)
+            opt = self.opt
+            opt._ensure_state(flat)
+            opt._step += 1
+            grp = opt.param_groups[0]
+            a = b.get("args")
+            if a is None:
+                a = b["args"] = _lib.MiTrainStepArgs()
+                a.logits, a.dlogits, a.loss_sums = b["logits"].data_ptr(), b["dlogits"].data_ptr(), b["sums"].data_ptr()
+                a.loss, a.workspace, a.do_adamw, a.grad_scale = b["loss"].data_ptr(), b["ws"].data_ptr(), 1, 1.0
+            a.params, a.grads, a.loss_accum = flat.data_ptr(), self._grad.data_ptr(), self._loss_accum.data_ptr()
+            a.exp_avg, a.exp_avg_sq = opt._m.data_ptr(), opt._v.data_ptr()
+            a.x, a.target, a.target_dtype, a.fold2 = x.data_ptr(), labels.data_ptr(), tcode, 1 if L.fold_label_two else 0
+            a.smooth_nr, a.smooth_dr, a.lambda_dice, a.lambda_ce = L.smooth_nr, L.smooth_dr, L.lambda_dice, L.lambda_ce
+            a.lr, (a.beta1, a.beta2), a.eps, a.weight_decay = grp["lr"], grp["betas"], grp["eps"], grp["weight_decay"]
+            a.step, a.seed = opt._step, seed
+            _lib.check(lib.mi_unet_train_step(plan.h, C.byref(a), st), "mi_unet_train_step")
+            return
+        nb, npix = x.shape[0], x[0].numel()
         plan.forward(flat, x, b["logits"], b["ws"], True, seed)
         _lib.check(lib.mi_dice_ce_loss_fwd(b["logits"].data_ptr(), labels.data_ptr(), tcode, 1 if L.fold_label_two else 0,
                                            nb, npix, L.smooth_nr, L.smooth_dr, L.lambda_dice, L.lambda_ce,
