@@ -139,6 +139,122 @@ def kernel_table(plan, nsteps):
     return rows
 
 
+CONV_KERNEL_TAGS = ("igemm", "conv2d_", "conv3d_", "wgrad_kernel", "wgrad_thick", "wgrad_thin", "wgrad_dma")
+
+
+def plan_roofline(plan, nprof, dtype="bf16", backward=(False, True)):
+    """Roofline entry of the dominant kernel (largest share of the instrumented kernel time) of `plan`, and the MFMA
+    utilisation of its convolution kernels, from the per-launch HIP-event times mi_unet_prof_collect accumulated over
+    `nprof` passes.  achieved = sum of the algorithmic work of that kernel's launches / sum of their durations."""
+    rows = {}
+    for bw in backward:
+        for s in plan.steps(bw):
+            if s["launches"] == 0:
+                continue
+            r = rows.setdefault(s["kernel"], dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
+            r["ms"] += s["total_ms"]
+            r["launches"] += s["launches"]
+            r["bytes"] += s["bytes"] * s["launches"]
+            if s["work_is_flops"]:
+                r["flops"] += s["work"] * s["launches"]
+    if not rows:
+        return None, None, rows
+    tot_ms = sum(r["ms"] for r in rows.values())
+    conv = {k: r for k, r in rows.items() if r["flops"] > 0 and any(t in k for t in CONV_KERNEL_TAGS)}
+    conv_s = sum(r["ms"] for r in conv.values()) / 1e3
+    mfma_util = round(sum(r["flops"] for r in conv.values()) / conv_s / MFMA_BF16_PEAK, 4) if conv_s else None
+    dom_name, dom = max(rows.items(), key=lambda kv: kv[1]["ms"])
+    sec = dom["ms"] / 1e3
+    ai = dom["flops"] / max(dom["bytes"], 1.0)
+    if dom["flops"] > 0 and ai > RIDGE and dtype == "bf16":
+        roof = {"bound": "mfma", "achieved": round(dom["flops"] / sec / 1e12, 2), "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s"}
+    else:
+        roof = {"bound": "hbm", "achieved": round(dom["bytes"] / sec / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s"}
+    roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
+    roof["traffic"] = None
+    roof["algorithmic_bytes_per_launch"] = round(dom["bytes"] / max(1, dom["launches"]))
+    roof["kernel"] = dom_name
+    roof["avg_launch_us"] = round(1e3 * dom["ms"] / dom["launches"], 2)
+    roof["launches_per_step"] = round(dom["launches"] / nprof, 1)
+    roof["share_of_kernel_time"] = round(dom["ms"] / tot_ms, 3)
+    return roof, mfma_util, rows
+
+
+def profiled(plan, nprof, fn):
+    """Runs fn() nprof times with every launch of `plan` bracketed by HIP events on its stream."""
+    lib = plan.lib
+    lib.mi_unet_prof_reset(plan.h)
+    lib.mi_unet_prof_enable(plan.h, 1)
+    for _ in range(nprof):
+        fn()
+    torch.cuda.synchronize()
+    lib.mi_unet_prof_collect(plan.h)
+    lib.mi_unet_prof_enable(plan.h, 0)
+
+
+def secondary_train(dims, size, batch, dev, dropout, steps=10, warmup=3, config=""):
+    """A side measurement of the training step on another workload of BASELINE.json (never `value`)."""
+    import unet_amd
+
+    ch = (16, 32, 64, 128, 256)
+    torch.manual_seed(0)
+    m = unet_amd.UNet(dims, 1, 1, ch, (2, 2, 2, 2), num_res_units=2, dropout=dropout, compute_dtype=torch.bfloat16).to(dev).train()
+    tr = unet_amd.Trainer(m, unet_amd.DiceLoss(sigmoid=True, fold_label_two=True),
+                          unet_amd.AdamW(m.parameters(), lr=5e-4, weight_decay=1e-5, model=m))
+    x, t = synthetic_batch(batch, (size,) * dims, 4321, dev)
+    for _ in range(warmup):
+        tr.step(x, t)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.step(x, t)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    plan = m._plan_for(x, True)
+    flops = plan.flops(False) + plan.flops(True)
+    nprof = min(steps, 5)
+    profiled(plan, nprof, lambda: tr.step(x, t))
+    roof, util, _ = plan_roofline(plan, nprof)
+    unit = "slices/s" if dims == 2 else "patches/s"
+    return {"workload": f"{dims}D U-Net ch 16-256 training, batch {batch} of {'x'.join([str(size)] * dims)}, bf16, dropout {dropout} ({config})",
+            "value": round(batch * steps / el, 2), "unit": unit, "steps": steps, "ms_per_step": round(1e3 * el / steps, 4),
+            "conv_gflop_per_step": round(flops / 1e9, 1), "conv_tflops_whole_step": round(flops / (el / steps) / 1e12, 1),
+            "mfma_util": util, "roofline": roof}
+
+
+def secondary_infer(dev, batch=32, size=512, roi=256, steps=10, warmup=3):
+    """Sliding-window evaluation (reference/train.py:128-153) of `batch` slices per step: side measurement with the
+    roofline entry of the dominant kernel of the forward pass."""
+    import unet_amd
+    from unet_amd.evaluator import VolumeEvaluator
+
+    ch = (16, 32, 64, 128, 256)
+    torch.manual_seed(0)
+    m = unet_amd.UNet(2, 1, 1, ch, (2, 2, 2, 2), num_res_units=2, dropout=0.1, compute_dtype=torch.bfloat16).to(dev).eval()
+    x, t = synthetic_batch(batch, (size, size), 4321, dev)
+    ev = VolumeEvaluator(m, (roi, roi), sw_batch_size=288, slices_per_call=32)
+    for _ in range(warmup):
+        ev.slice_dice(x, t)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ev.slice_dice(x, t)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    nwin = len(unet_amd.window_starts([size, size], [roi, roi], 0.25))
+    plans = [p for p in m._plans.values()]
+    flops = sum(p.flops(False) for p in plans if p.batch == batch * nwin) or batch * nwin * 1.509e9
+    plan = max(plans, key=lambda p: p.batch)
+    nprof = min(steps, 3)
+    profiled(plan, nprof, lambda: ev.slice_dice(x, t))
+    roof, util, _ = plan_roofline(plan, nprof, backward=(False,))
+    return {"workload": f"sliding-window inference + hard Dice, {batch} slices of {size}x{size} per step, roi {roi}, overlap 0.25 ({nwin} windows per "
+                        f"slice, 288 windows per model call), bf16 (BASELINE.json configs[4] shape, one GPU)",
+            "value": round(batch * steps / el, 2), "unit": "slices/s", "steps": steps, "ms_per_step": round(1e3 * el / steps, 4),
+            "conv_gflop_per_step": round(flops / 1e9, 1), "conv_tflops_whole_step": round(flops / (el / steps) / 1e12, 1),
+            "mfma_util": util, "roofline": roof}
+
+
 def launch_ranks(n, argv):
     """Parent of a multi-GPU run started without torchrun: starts `n` ranks of this script under
     torch.distributed.run (one per GPU), passes rank 0's JSON line through and fails when any rank fails or the
@@ -211,6 +327,8 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-reference-network", action="store_true",
                     help="skip the side measurement on the channel widths of reference/train.py:82 (32-512)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the side measurements of the other BASELINE.json workloads (3-D patches, inference, batch 8 x 256^2)")
     ap.add_argument("--no-overlap", action="store_true", help="all-reduce after the whole backward")
     ap.add_argument("--host-input", action="store_true",
                     help="train mode: every step's batch starts in pinned host memory (fp32 image and label) and is copied "
@@ -389,6 +507,14 @@ def main():
 
     plan = model._plan_for(x, True)
     flops_step = plan.flops(False) + plan.flops(True)
+    if args.dims == 3:
+        which_config = "BASELINE.json configs[3]" if (args.size, args.channels) == (96, "16,32,64,128,256") else "3-D variant of BASELINE.json configs[3]"
+    elif (args.size, args.batch, args.channels, args.dtype) == (512, 32, "16,32,64,128,256", "bf16"):
+        which_config = "BASELINE.json configs[1]" if world == 1 else "BASELINE.json configs[2]"
+    elif (args.size, args.batch, args.channels) == (256, 8, "16,32,64,128,256"):
+        which_config = "shape of BASELINE.json configs[0] on the GPU"
+    else:
+        which_config = "variant of BASELINE.json configs[1]"
     out = {
         "metric": f"train slices/sec (whole node) 2D U-Net {args.size}x{args.size} {args.dtype}" if args.dims == 2 else "train patches/sec (whole node) 3D U-Net",
         "value": round(value, 2), "unit": "slices/s" if args.dims == 2 else "patches/s",
@@ -396,7 +522,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{args.dims}D residual U-Net ch {'-'.join(map(str, channels))}, 2 res units, "
                                f"{'x'.join(map(str, sp))} 1-ch {'slices' if args.dims == 2 else 'patches'}, "
-                               f"batch {args.batch}/GPU, Dice loss, AdamW (BASELINE.json configs[1])",
+                               f"batch {args.batch}/GPU, Dice loss, AdamW ({which_config})",
                    "global_batch": world * args.batch, "parallelism": f"dp{world}", "dropout": args.dropout,
                    "conv_gflop_per_step_per_gpu": round(flops_step / 1e9, 1)},
         "mean_loss": round(last_loss, 5),
@@ -500,6 +626,17 @@ def main():
                                     "steps": n2, "ms_per_step": round(1e3 * e2 / n2, 4),
                                     "conv_gflop_per_step_per_gpu": round(f2 / 1e9, 1),
                                     "conv_tflops_whole_step": round(f2 / (e2 / n2) / 1e12, 1)}
+
+    if (rank == 0 and world == 1 and not args.no_secondary and args.dims == 2 and args.dtype == "bf16"
+            and (args.size, args.batch, args.channels) == (512, 32, "16,32,64,128,256")):
+        # the other single-GPU workloads BASELINE.json names, measured after the timed region (side figures, never `value`)
+        del trainer, opt, model, plan
+        torch.cuda.empty_cache()
+        out["secondary"] = {
+            "train_3d_96": secondary_train(3, 96, 4, dev, args.dropout, config="BASELINE.json configs[3]"),
+            "infer_sliding_window": secondary_infer(dev),
+            "train_2d_256_b8": secondary_train(2, 256, 8, dev, args.dropout, config="shape of BASELINE.json configs[0]: the reference's own batch, reference/config.py:69"),
+        }
 
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -142,6 +142,31 @@ def test_fused_step_equals_autograd_step_fp32(dev):
     assert float((ma.flat_parameters() - mb.flat_parameters()).abs().max()) < 2.5e-3
 
 
+@pytest.mark.parametrize("dt,drop", [(torch.float32, 0.0), (torch.bfloat16, 0.1)], ids=["fp32", "bf16_dropout"])
+def test_one_call_step_equals_the_split_calls_bit_for_bit(dev, dt, drop):
+    """mi_unet_train_step (one library call per step) against forward + loss + backward + AdamW as separate calls:
+    same kernels in the same order, so parameters, gradients, moments and the loss sum agree exactly over three steps."""
+    x, t = _batch(4, 128, dev)
+
+    def run(split):
+        torch.manual_seed(4)
+        m = unet_amd.UNet(2, 1, 1, CH, (2, 2, 2, 2), num_res_units=2, dropout=drop, compute_dtype=dt).to(dev).train()
+        m.seed_dropout(31)
+        o = unet_amd.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-5, model=m)
+        sched = torch.optim.lr_scheduler.StepLR(o, step_size=1, gamma=0.5)
+        tr = unet_amd.Trainer(m, unet_amd.DiceCELoss(sigmoid=True, fold_label_two=True), o, split_calls=split)
+        for _ in range(3):
+            tr.step(x, t)
+            sched.step()                       # the learning rate of the next step is read from the optimizer each time
+        torch.cuda.synchronize()
+        return m.flat_parameters().clone(), tr._grad.clone(), o._m.clone(), o._v.clone(), tr.loss_sum(), o._step
+
+    a, b = run(False), run(True)
+    for u, v in zip(a[:4], b[:4]):
+        assert torch.equal(u, v)
+    assert a[4] == b[4] and a[4] > 0 and a[5] == b[5] == 3
+
+
 def test_3d_patch_permutation_and_direction_full_size(dev):
     """The 3-D benchmark shape (4 patches of 96^3, channels 16-256): permuting the batch permutes the logits bit
     for bit (bf16), and the fp32 gradient agrees with a central difference of the loss along a random direction."""
