@@ -231,6 +231,8 @@ struct Builder {
         snprintf(kb, sizeof(kb), "igemm_kernel<%s,%d,%d>", u.dt ? "BF16" : "F32", cps, nfrag);
         if (conv2d_dma_enabled() && conv2d_dma_applicable(u.dt, p))
             conv2d_dma_label(u.dt, p, kb, sizeof(kb));
+        else
+            igemm_dma_label(u.dt, p, kb, sizeof(kb));
         s.kernel = kb;
         double bpix = (double)p.bd[0] * p.bd[1] * p.bd[2] * u.nb;
         s.work = 2.0 * bpix * (double)(*ntaps_out) * K * N; s.work_is_flops = 1;
@@ -260,6 +262,12 @@ struct Builder {
                 const size_t kp = alloc((size_t)ks * npo * N * sizeof(float));
                 p.ksplit = ks;
                 REL(s, p, kpart, B_ARENA, kp);
+                {   // a split layer leaves the compile-time 2-D kernels: name the kernel that serves it now
+                    char kb2[96];
+                    snprintf(kb2, sizeof(kb2), "igemm_kernel<%s,%d,%d>", u.dt ? "BF16" : "F32", cps, nfrag);
+                    igemm_dma_label(u.dt, p, kb2, sizeof(kb2));
+                    s.kernel = kb2;
+                }
                 const std::string lname = s.layer;
                 const Step main_step = s;              // copy: push() may move the vector's storage
                 Step& f = push(list, K_KFINISH, lname + " (finish)");

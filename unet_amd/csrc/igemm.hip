@@ -1055,6 +1055,7 @@ int launch_igemm(int dtype, const IgemmParams& p, hipStream_t st) {
         MI_CHECK(!p.out1 || (p.out0_c % 16 == 0 && p.out0_c > 0 && p.out0_c < p.N), "first-destination channel count must be a multiple of 16");
         return launch_conv2d_dma(dtype, p, st);
     }
+    if (igemm_dma_applicable(dtype, p)) return launch_igemm_dma(dtype, p, st);
     int cps, nfrag;
     igemm_config(dtype, p, &cps, &nfrag);
     const int esz = dtype ? 2 : 4;
@@ -1184,7 +1185,7 @@ int launch_wgrad(int dtype, const WgradParams& p, hipStream_t st) {
 // Workgroups the forward / dgrad launch of `p` would use without a contraction split, and its contraction chunks
 void igemm_parallelism(int dtype, const IgemmParams& p, long long* wgs, int* nkc) {
     int cps, nfrag;
-    igemm_config(dtype, p, &cps, &nfrag);
+    if (!igemm_dma_config(dtype, p, &cps, &nfrag)) igemm_config(dtype, p, &cps, &nfrag);
     *wgs = (long long)p.nb * p.ntile[0] * p.ntile[1] * p.ntile[2] * p.nphase * (p.N / (16 * nfrag));
     const int kce = cps * 16 / (dtype ? 2 : 4);
     *nkc = (p.K + kce - 1) / kce;

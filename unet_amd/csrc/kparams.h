@@ -153,6 +153,10 @@ int launch_wgrad(int dtype, const WgradParams& p, hipStream_t st);
 bool conv2d_dma_applicable(int dtype, const IgemmParams& p);   // conv2d.hip: asynchronously staged 2-D kernels
 int launch_conv2d_dma(int dtype, const IgemmParams& p, hipStream_t st);
 bool conv2d_dma_enabled();
+bool igemm_dma_applicable(int dtype, const IgemmParams& p);   // igemm_dma.hip: asynchronously staged kernel for any tile geometry (unit gather stride)
+bool igemm_dma_config(int dtype, const IgemmParams& p, int* cps, int* nfrag);
+int launch_igemm_dma(int dtype, const IgemmParams& p, hipStream_t st);
+void igemm_dma_label(int dtype, const IgemmParams& p, char* buf, size_t n);
 void conv2d_dma_label(int dtype, const IgemmParams& p, char* buf, size_t n);   // step-table name of the kernel that serves p
 int launch_wgrad_dma(int dtype, const WgradParams& p, int ff, int sf, int wf, int wsn, hipStream_t st);   // 1: shape not served
 int launch_wgrad_thick(int dtype, const WgradParams& p, int ff, int sf, int wf, int wsn, hipStream_t st);   // wgrad3.hip; 1: shape not served
