@@ -23,6 +23,20 @@ elif [ "$STAGE" = sq ]; then
   MI_NO_SIDE_STREAM=1 timeout -s KILL 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES -d $OUT/sq -o pmc --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-reference-network > $OUT/sq.log 2>&1 || exit 1
   cp "$(find $OUT/sq -name '*counter_collection.csv' | head -1)" $OUT/pmc_sq.csv || exit 1
   rm -rf $OUT/sq
+elif [ "$STAGE" = level0 ]; then
+  # issue / wait / store-path counters per kernel (three passes: SQ, TCC write side, TCP stalls); read with
+  # scripts/pmc_by_kernel.py for the first-layer convolution and the 16-channel scatter layer against the norm kernels
+  P="--steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-reference-network --no-secondary"
+  for pass in sq tcc tcp; do
+    if [ $pass = sq ]; then C="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD";
+    elif [ $pass = tcc ]; then C="TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_STALL_sum TCC_TOO_MANY_EA_WRREQS_STALL_sum TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum";
+    else C="TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_WRITE_TAGCONFLICT_STALL_CYCLES_sum"; fi
+    rm -rf $OUT/l0_$pass
+    MI_NO_SIDE_STREAM=1 timeout -s KILL 200 rocprofv3 --pmc $C -d $OUT/l0_$pass -o pmc --output-format csv -- python3 bench.py $P > $OUT/l0_$pass.log 2>&1 || { tail -5 $OUT/l0_$pass.log; exit 1; }
+    python3 scripts/pmc_by_kernel.py "$(find $OUT/l0_$pass -name '*counter_collection.csv' | head -1)" > $OUT/pmc_l0_$pass.csv || exit 1
+    rm -rf $OUT/l0_$pass
+  done
+  head -30 $OUT/pmc_l0_sq.csv
 elif [ "$STAGE" = alt ]; then
   for w in 3d infer ref; do
     if [ $w = 3d ]; then ARGS="--dims 3 --size 96 --batch 4"; elif [ $w = ref ]; then ARGS="--channels 32,64,128,256,512"; else ARGS="--mode infer"; fi

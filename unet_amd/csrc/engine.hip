@@ -16,6 +16,7 @@
 #include <stdio.h>
 
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <string>
 #include <type_traits>
@@ -125,6 +126,8 @@ struct mi_unet {
     bool prof = false;
     std::vector<ProfEvent> events;
     int rd[9][3]; long long rp[9];
+    // MI_HOST_TIMING=1: wall time the host spends inside mi_unet_train_step (enqueue only), reported when the plan goes
+    double host_ns = 0; long long host_calls = 0;
 };
 
 namespace {
@@ -1083,6 +1086,17 @@ int run_list(mi_unet& u, std::vector<Step>& list, int backward, int bucket, char
     bool pending = false;
     bool pack_first_pending = false, pack_first_done = false;
     size_t nside = 0;
+    // Weight gradients per fork of the side stream.  An event record plus a stream wait costs the host about as much
+    // as three kernel launches; on a large batch every weight gradient forks on its own (it then starts beside the
+    // kernels that suit it best: measured faster), on small workloads, where the host's enqueue time is what bounds
+    // the step, several weight gradients share one fork (they are launched together behind the last one's producer:
+    // nothing they read is ever overwritten, the workspace has no reuse).
+    int fork_batch = 1;
+    if (backward) {
+        static const int env = getenv("MI_FORK_BATCH") ? atoi(getenv("MI_FORK_BATCH")) : 0;
+        fork_batch = env > 0 ? env : ((long long)u.nb * u.rp[1] < (1ll << 20) ? 4 : 1);
+    }
+    Step* deferred[16]; int ndeferred = 0;
     auto fork = [&]() -> int {      // the side stream waits for everything enqueued on the main stream so far
         if (nside >= u.side_ev.size()) {
             hipEvent_t e;
@@ -1100,9 +1114,25 @@ int run_list(mi_unet& u, std::vector<Step>& list, int backward, int bucket, char
         pending = false;
         return 0;
     };
+    auto flush_deferred = [&]() -> int {     // one fork for all the weight gradients collected so far
+        if (!ndeferred) return 0;
+        if (int r = fork()) return r;
+        for (int k = 0; k < ndeferred; ++k)
+            if (int r = run_step(u, *deferred[k], bases, training, seed, u.side)) return r;
+        ndeferred = 0; pending = true;
+        return 0;
+    };
     for (size_t i = 0; i < list.size(); ++i) {
         Step& s = list[i];
         if (bucket >= 0 && s.bucket != bucket) continue;
+        if (side && backward && fork_batch > 1) {
+            if (is_wgrad_kind(s.kind)) {
+                deferred[ndeferred++] = &s;
+                if (ndeferred >= fork_batch || ndeferred >= 16) { if (int r = flush_deferred()) return r; }
+                continue;
+            }
+            if (s.kind == K_REDUCE) { if (int r = flush_deferred()) return r; }     // the reduction follows its slabs on the side stream
+        }
         ProfEvent ev;
         if (u.prof) {
             MI_HIP(hipEventCreate(&ev.a)); MI_HIP(hipEventCreate(&ev.b));
@@ -1131,6 +1161,7 @@ int run_list(mi_unet& u, std::vector<Step>& list, int backward, int bucket, char
             u.events.push_back(ev);
         }
     }
+    if (int r = flush_deferred()) return r;
     if (pending) { if (int r = join()) return r; }
     return 0;
 }
@@ -1180,6 +1211,7 @@ int mi_unet_create(const mi_unet_cfg* cfg, mi_unet** out) {
 
 void mi_unet_destroy(mi_unet* u) {
     if (!u) return;
+    if (u->host_calls) fprintf(stderr, "[libunet_mi355] host time inside mi_unet_train_step: %.1f us per call over %lld calls\n", u->host_ns / 1e3 / u->host_calls, u->host_calls);
     for (ProfEvent& e : u->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (hipEvent_t e : u->side_ev) (void)hipEventDestroy(e);
     if (u->join_ev) (void)hipEventDestroy(u->join_ev);
@@ -1235,7 +1267,16 @@ int mi_unet_backward(mi_unet* u, const float* params, const float* x, const floa
     return run_list(*u, u->bwd, 1, bucket, bases, training, seed, st);
 }
 
+static int train_step_body(mi_unet* u, const mi_train_step_args* a, void* stream);
 int mi_unet_train_step(mi_unet* u, const mi_train_step_args* a, void* stream) {
+    static const bool timing = getenv("MI_HOST_TIMING") != nullptr;
+    if (!timing) return train_step_body(u, a, stream);
+    const auto t0 = std::chrono::steady_clock::now();
+    const int r = train_step_body(u, a, stream);
+    if (u) { u->host_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count(); u->host_calls += 1; }
+    return r;
+}
+static int train_step_body(mi_unet* u, const mi_train_step_args* a, void* stream) {
     MI_CHECK(u && a, "null argument");
     MI_CHECK(a->params && a->x && a->target && a->logits && a->dlogits && a->loss_sums && a->loss && a->grads && a->workspace,
              "null buffer");

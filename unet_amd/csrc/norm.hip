@@ -339,6 +339,129 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const NormParams p)
         unit(*reinterpret_cast<const uint4*>(xb + ((unsigned)pix0 * xs + cb)), *reinterpret_cast<const uint4*>(gb + ((unsigned)pix0 * gs + cb)), pix0);
 }
 
+// Backward in ONE launch for small images: a workgroup owns one image and NORM_SMALL_CG channels, keeps its share of
+// x and dy in registers between the reduction and the apply step (at most NORM_SMALL_K sweeps of 256 / (vectors per
+// pixel of the group) pixels), reduces inside the workgroup (no global accumulators, no second pass over memory) and
+// writes dx.  For tensors of a few hundred kilobytes the two-kernel form is two dependent launches of a few
+// microseconds each with nothing to do; at the sizes of a large batch it loses (32 bytes per pixel and workgroup is a
+// poor access shape), so the launcher takes it only for small tensors.  Same arithmetic per element as the pair.
+constexpr int NORM_SMALL_CG = 16;
+constexpr int NORM_SMALL_K = 16;
+template <class TR, bool DROP>
+__global__ __launch_bounds__(256) void norm_bwd_small_kernel(const NormParams p) {
+    constexpr int VEC = TR::VEC, ESZ = TR::ESZ;
+    constexpr int CVW = NORM_SMALL_CG / VEC;      // 16-byte vectors per pixel of the channel group (2 or 4)
+    constexpr int ROWS = 256 / CVW;               // pixels per sweep
+    __shared__ float mom[NORM_SMALL_CG * 2];
+    __shared__ float part[256 * 2 * VEC];
+    __shared__ float red_da[4];
+    const int img = blockIdx.y;
+    const int c0 = blockIdx.x * NORM_SMALL_CG;
+    if (threadIdx.x < NORM_SMALL_CG) {
+        const int ch = c0 + threadIdx.x;
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int sl = 0; sl < MI_NSLOT; ++sl) {
+            const double* q = p.stats + (((size_t)img * MI_NSLOT + sl) * p.c + ch) * 2;
+            s1 += q[0]; s2 += q[1];
+        }
+        const double mean = s1 / (double)p.npix;
+        double var = s2 / (double)p.npix - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        mom[threadIdx.x * 2] = (float)mean;
+        mom[threadIdx.x * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
+    }
+    const int cv = threadIdx.x % CVW, prow = threadIdx.x / CVW;
+    const int ch0 = c0 + cv * VEC;
+    const size_t img_pix = (size_t)img * p.npix;
+    const char* xb = p.x + (img_pix * p.x_pitch + p.x_coff) * ESZ;
+    const char* gb = p.dy + (img_pix * p.dy_pitch + p.dy_coff) * ESZ;
+    char* ob = p.out + (img_pix * p.out_pitch + p.out_coff) * ESZ;
+    const unsigned xs = p.x_pitch * ESZ, gs = p.dy_pitch * ESZ, os = p.out_pitch * ESZ, cb = ch0 * ESZ;
+    // every load of the image share is issued before the first use
+    uint4 xr[NORM_SMALL_K], gr[NORM_SMALL_K];
+#pragma unroll
+    for (int k = 0; k < NORM_SMALL_K; ++k) {
+        const int pix = prow + k * ROWS;
+        xr[k] = make_uint4(0u, 0u, 0u, 0u); gr[k] = xr[k];
+        if (pix < p.npix) {
+            xr[k] = *reinterpret_cast<const uint4*>(xb + ((unsigned)pix * xs + cb));
+            gr[k] = *reinterpret_cast<const uint4*>(gb + ((unsigned)pix * gs + cb));
+        }
+    }
+    __syncthreads();
+    const float alpha = *p.alpha;
+    const DropKeys dk = dropout_keys(p.seed, p.layer, img, p.drop_thresh);
+    const unsigned cq = p.c / 4, gq = ch0 / 4;
+    const float scale = p.drop_scale;
+    float mean[VEC], rstd[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { mean[e] = mom[(cv * VEC + e) * 2]; rstd[e] = mom[(cv * VEC + e) * 2 + 1]; }
+    float s12[2 * VEC], da = 0.f;
+#pragma unroll
+    for (int e = 0; e < 2 * VEC; ++e) s12[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < NORM_SMALL_K; ++k) {
+        const int pix = prow + k * ROWS;
+        if (pix < p.npix) {
+            float x[VEC], dy[VEC];
+            bool keep[VEC];
+            unpack_vec<TR>(xr[k], x); unpack_vec<TR>(gr[k], dy);
+            if (DROP) {
+#pragma unroll
+                for (int q = 0; q < VEC / 4; ++q) dropout_keep4(dk, (unsigned)pix * cq + gq + q, keep + 4 * q);
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float xh = (x[e] - mean[e]) * rstd[e];
+                float d = xh, sc = 1.f;
+                if (DROP) { sc = keep[e] ? scale : 0.f; d = xh * sc; }
+                const float gd = dy[e] * (d > 0.f ? 1.f : alpha);
+                da += dy[e] * fminf(d, 0.f);
+                const float gh = DROP ? gd * sc : gd;
+                s12[e] += gh; s12[VEC + e] += gh * xh;
+            }
+        }
+    }
+    da = wave_sum(da);
+    if ((threadIdx.x & 63) == 0) red_da[threadIdx.x >> 6] = da;
+    NormLane l;
+    l.cv = cv; l.prow = prow; l.rows = ROWS; l.ch0 = ch0; l.pbeg = 0; l.pend = p.npix; l.active = true;
+    sum_rows<VEC>(s12, part, l, CVW);             // ends with a barrier: part[cv * 2 VEC + e] holds the totals, red_da is visible
+    if (threadIdx.x == 0 && p.dalpha) {
+        const float v = ((red_da[0] + red_da[1]) + red_da[2]) + red_da[3];
+        if (p.dalpha_slots) p.dalpha[img * gridDim.x + blockIdx.x] = v;
+        else atomicAdd(p.dalpha, v);
+    }
+    const float inv_n = 1.0f / (float)p.npix;
+    float b1[VEC], b2[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { b1[e] = part[cv * 2 * VEC + e] * inv_n; b2[e] = part[cv * 2 * VEC + VEC + e] * inv_n; }
+#pragma unroll
+    for (int k = 0; k < NORM_SMALL_K; ++k) {
+        const int pix = prow + k * ROWS;
+        if (pix < p.npix) {
+            float x[VEC], dy[VEC], o[VEC];
+            bool keep[VEC];
+            unpack_vec<TR>(xr[k], x); unpack_vec<TR>(gr[k], dy);
+            if (DROP) {
+#pragma unroll
+                for (int q = 0; q < VEC / 4; ++q) dropout_keep4(dk, (unsigned)pix * cq + gq + q, keep + 4 * q);
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float xh = (x[e] - mean[e]) * rstd[e];
+                float d = xh, sc = 1.f;
+                if (DROP) { sc = keep[e] ? scale : 0.f; d = xh * sc; }
+                float gh = dy[e] * (d > 0.f ? 1.f : alpha);
+                if (DROP) gh *= sc;
+                o[e] = rstd[e] * (gh - b1[e] - xh * b2[e]);
+            }
+            store_vec<TR>(ob + ((unsigned)pix * os + cb), o);
+        }
+    }
+}
+
 // ---- one-channel fp32 planar variants (top of the decoder) ------------------------
 // tensors are [nb][npix] fp32; four consecutive pixels per lane.
 // W = 4: four consecutive pixels per lane as one 16-byte access (npix a multiple of 4; they are exactly one
@@ -494,7 +617,17 @@ static int norm_blocks(int npix, int c, int vec, int sweeps, int cap) {
     return g;
 }
 
-int norm_bwd_reduce_blocks(int npix, int c) {
+// The one-launch backward serves small tensors only: images of at most 256 / (vectors per pixel of a 16-channel group)
+// x 16 pixels (bf16 2048, fp32 1024) and at most `max_elems` elements in the whole tensor (MI_NORM_BWD_SMALL_MAX, default
+// 2^21: at the sizes of a large batch the two streaming kernels are faster; 0 switches the kernel off).
+static bool norm_bwd_small_ok(int dtype, const NormParams& p) {
+    static const long long max_elems = getenv("MI_NORM_BWD_SMALL_MAX") ? atoll(getenv("MI_NORM_BWD_SMALL_MAX")) : (1ll << 21);
+    const int rows = 256 / (NORM_SMALL_CG / (dtype ? 8 : 4));
+    return p.c >= NORM_SMALL_CG && p.c % NORM_SMALL_CG == 0 && p.npix <= rows * NORM_SMALL_K && (long long)p.nb * p.npix * p.c <= max_elems;
+}
+
+// workgroups per image of the backward reduction pass
+static int norm_bwd_reduce_grid(int npix, int c) {
     if (c == 1) {
         int g = (npix + 2047) / 2048;
         return g < 1 ? 1 : g > 128 ? 128 : g;
@@ -504,6 +637,14 @@ int norm_bwd_reduce_blocks(int npix, int c) {
     const int g = norm_blocks(npix, c, 4, 32, 256);
     const int gmin = norm_blocks(npix, c, 4, 4, 16);
     return g > gmin ? g : gmin;
+}
+
+// slope-gradient partials per image a caller has to provide (zeroed: whichever kernel runs writes its workgroups'
+// partials to the first slots and leaves the rest alone): the larger of the two kernels' workgroup counts
+int norm_bwd_reduce_blocks(int npix, int c) {
+    const int g = norm_bwd_reduce_grid(npix, c);
+    const int gs = (c >= NORM_SMALL_CG && c % NORM_SMALL_CG == 0) ? c / NORM_SMALL_CG : 0;
+    return g > gs ? g : gs;
 }
 
 // planar kernels: 16-byte accesses when every image starts on a 16-byte boundary
@@ -563,7 +704,7 @@ int launch_norm_bwd(int dtype, const NormParams& p, hipStream_t st) {
     if (p.c == 1) {
         MI_CHECK(dtype == 0 && p.x_pitch == 1 && p.out_pitch == 1 && p.dy_pitch == 1, "one-channel tensors are planar fp32");
         const bool v4 = planar_v4(p);
-        const int gx = norm_bwd_reduce_blocks(p.npix, 1);
+        const int gx = norm_bwd_reduce_grid(p.npix, 1);
         NORM1_CASE(norm1_bwd_reduce_kernel, dim3(gx, p.nb));
         if (int r = check_launch("norm1_bwd_reduce")) return r;
         int ga = (p.npix / (v4 ? 4 : 1) + 511) / 512; if (ga > 256) ga = 256; if (ga < 1) ga = 1;
@@ -573,10 +714,21 @@ int launch_norm_bwd(int dtype, const NormParams& p, hipStream_t st) {
     const int vec = dtype ? 8 : 4;
     MI_CHECK(p.c % vec == 0, "channels must be a multiple of the 16-byte vector");
     MI_CHECK(p.c / vec <= 256, "too many channels for the reduction kernel");
+    const bool drop = p.drop_thresh != 0;
+    if (norm_bwd_small_ok(dtype, p)) {
+        const dim3 gs(p.c / NORM_SMALL_CG, p.nb);
+        if (dtype) {
+            if (drop) hipLaunchKernelGGL((norm_bwd_small_kernel<BF16, true>), gs, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((norm_bwd_small_kernel<BF16, false>), gs, dim3(256), 0, st, p);
+        } else {
+            if (drop) hipLaunchKernelGGL((norm_bwd_small_kernel<F32, true>), gs, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((norm_bwd_small_kernel<F32, false>), gs, dim3(256), 0, st, p);
+        }
+        return check_launch("norm_bwd_small");
+    }
     const size_t lds = (size_t)p.c * 4 * sizeof(float);
     const size_t lds_r = ((size_t)p.c * 2 + 256 * 2 * vec) * sizeof(float);
-    const int gr = norm_bwd_reduce_blocks(p.npix, p.c);
-    const bool drop = p.drop_thresh != 0;
+    const int gr = norm_bwd_reduce_grid(p.npix, p.c);
     if (dtype) {
         if (drop) hipLaunchKernelGGL((norm_bwd_reduce_kernel<BF16, true>), dim3(gr, p.nb), dim3(256), lds_r, st, p);
         else hipLaunchKernelGGL((norm_bwd_reduce_kernel<BF16, false>), dim3(gr, p.nb), dim3(256), lds_r, st, p);
