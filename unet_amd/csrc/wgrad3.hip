@@ -153,9 +153,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_thick_kernel(const WgradParams p
         asm volatile("" ::: "memory");
         if (j + 1 < nstage) issue_stage(j + 1);
         const char* sm = smem + (j & 1) * SLOT;
-#pragma unroll 1
-        for (int ks = 0; ks < 4; ++ks) {
-            uint4 afr[2];
+        // One software-pipelined stream of 4 k-steps x 9 taps: the fixed-operand fragments of the next k-step and the
+        // shifted-operand fragments of the next tap are requested before the MFMAs of the current tap are issued (two
+        // register sets each).  With one workgroup per CU (the side-stream launches are sized that way) a wave has
+        // nobody to hide its LDS latency behind; a single fragment set made every tap wait for its own reads.
+        auto load_a = [&](int ks, uint4 (&afr)[2]) {
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(sm + fa0[0][a] + ks * 32 * ROWB));
@@ -163,28 +165,40 @@ __global__ __launch_bounds__(256, 2) void wgrad_thick_kernel(const WgradParams p
                 v8s f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 afr[a] = __builtin_bit_cast(uint4, f);
             }
-            if (do_bias) {
-                const uint4 ones = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+        };
+        auto load_b = [&](int ks, int t, uint4 (&bfr)[2]) {
+            const int dy = t / 3, dx = t % 3;
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
-                    accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, afr[a]), __builtin_bit_cast(v8bf, ones), accb[a], 0, 0, 0);
+            for (int b = 0; b < 2; ++b) {
+                v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(sm + sa0[0][dx][b] + (2 * ks + dy) * PD * ROWB));
+                v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(sm + sa0[1][dx][b] + (2 * ks + dy) * PD * ROWB));
+                v8s f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                bfr[b] = __builtin_bit_cast(uint4, f);
             }
+        };
+        uint4 aq[2][2], bq[2][2];
+        load_a(0, aq[0]);
+        load_b(0, 0, bq[0]);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const int dy = t / 3, dx = t % 3;
-                uint4 bfr[2];
+                const int step = ks * NT + t;
+                if (t + 1 < NT) load_b(ks, t + 1, bq[(step + 1) & 1]);
+                else if (ks + 1 < 4) { load_a(ks + 1, aq[(ks + 1) & 1]); load_b(ks + 1, 0, bq[(step + 1) & 1]); }
+                __builtin_amdgcn_sched_barrier(0);       // keeps the requests of the next step in front of the MFMAs of this one
+                if (t == 0 && do_bias) {
+                    const uint4 ones = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(sm + sa0[0][dx][b] + (2 * ks + dy) * PD * ROWB));
-                    v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(sm + sa0[1][dx][b] + (2 * ks + dy) * PD * ROWB));
-                    v8s f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    bfr[b] = __builtin_bit_cast(uint4, f);
+                    for (int a = 0; a < 2; ++a)
+                        accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, aq[ks & 1][a]), __builtin_bit_cast(v8bf, ones), accb[a], 0, 0, 0);
                 }
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
                     for (int b = 0; b < 2; ++b)
-                        acc[t][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, afr[a]), __builtin_bit_cast(v8bf, bfr[b]), acc[t][a][b], 0, 0, 0);
+                        acc[t][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, aq[ks & 1][a]), __builtin_bit_cast(v8bf, bq[step & 1][b]), acc[t][a][b], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
