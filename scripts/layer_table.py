@@ -6,7 +6,7 @@ import sys
 RIDGE = 2.5e15 / 8.0e12
 rows = []
 for line in open(sys.argv[1]):
-    m = re.match(r"\s+(fwd|bwd) (.+?)\s{2,}(\S+)\s+([\d.]+) us\s+([\d.]+) TF/s\s+([\d.]+) GB/s", line)
+    m = re.match(r"\s+(fwd|bwd) (.+?)\s+(\S+)\s+([\d.]+) us\s+([\d.]+) TF/s\s+([\d.]+) GB/s", line)
     if not m:
         continue
     ps, layer, kern, us, tf, gb = m.group(1), m.group(2).strip(), m.group(3), float(m.group(4)), float(m.group(5)), float(m.group(6))

@@ -4,7 +4,7 @@
 #   sq    : one pass of eight SQ counters on a single stream
 #   trace : kernel traces (single stream and production schedule) and bench.py's own tables
 #   alt   : the secondary workloads (3-D training, sliding-window inference, the 32-512 channel widths of
-#           reference/train.py:82): kernel stats, bench JSON, per-layer table
+#           reference/train.py:82, 8 slices of 256 x 256): kernel stats, bench JSON, per-layer table
 set -o pipefail
 STAGE=${1:-trace}
 OUT=gpurun_out/prof
@@ -13,14 +13,14 @@ cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 if [ "$STAGE" = pmc ]; then
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf $OUT/pmc_$c
-    timeout -s KILL 200 rocprofv3 --pmc $c -d $OUT/pmc_$c -o pmc --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-reference-network > $OUT/pmc_$c.log 2>&1 || exit 1
+    timeout -s KILL 200 rocprofv3 --pmc $c -d $OUT/pmc_$c -o pmc --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-reference-network --no-secondary > $OUT/pmc_$c.log 2>&1 || exit 1
     cp "$(find $OUT/pmc_$c -name '*counter_collection.csv' | head -1)" $OUT/pmc_$c.csv || exit 1
     rm -rf $OUT/pmc_$c
   done
   ls -la $OUT
 elif [ "$STAGE" = sq ]; then
   rm -rf $OUT/sq
-  MI_NO_SIDE_STREAM=1 timeout -s KILL 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES -d $OUT/sq -o pmc --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-reference-network > $OUT/sq.log 2>&1 || exit 1
+  MI_NO_SIDE_STREAM=1 timeout -s KILL 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES -d $OUT/sq -o pmc --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-reference-network --no-secondary > $OUT/sq.log 2>&1 || exit 1
   cp "$(find $OUT/sq -name '*counter_collection.csv' | head -1)" $OUT/pmc_sq.csv || exit 1
   rm -rf $OUT/sq
 elif [ "$STAGE" = level0 ]; then
@@ -38,10 +38,10 @@ elif [ "$STAGE" = level0 ]; then
   done
   head -30 $OUT/pmc_l0_sq.csv
 elif [ "$STAGE" = alt ]; then
-  for w in 3d infer ref; do
-    if [ $w = 3d ]; then ARGS="--dims 3 --size 96 --batch 4"; elif [ $w = ref ]; then ARGS="--channels 32,64,128,256,512"; else ARGS="--mode infer"; fi
+  for w in 3d infer ref b8; do
+    if [ $w = 3d ]; then ARGS="--dims 3 --size 96 --batch 4"; elif [ $w = ref ]; then ARGS="--channels 32,64,128,256,512"; elif [ $w = b8 ]; then ARGS="--size 256 --batch 8"; else ARGS="--mode infer"; fi
     rm -rf $OUT/a_$w
-    timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $OUT/a_$w -o r --output-format csv -- python3 bench.py $ARGS --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-reference-network > $OUT/trace_$w.log 2>&1 || exit 1
+    timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $OUT/a_$w -o r --output-format csv -- python3 bench.py $ARGS --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-reference-network --no-secondary > $OUT/trace_$w.log 2>&1 || exit 1
     cp "$(find $OUT/a_$w -name '*kernel_stats.csv' | head -1)" $OUT/kernel_stats_$w.csv || exit 1
     rm -rf $OUT/a_$w
     BENCH_LAYERS=1 timeout -k 10 300 python bench.py $ARGS --no-cpu-baseline --no-reference-network > $OUT/bench_$w.json 2> $OUT/per_layer_$w.txt || exit 1
@@ -49,9 +49,9 @@ elif [ "$STAGE" = alt ]; then
   done
 else
   rm -rf $OUT/t1 $OUT/t2
-  MI_NO_SIDE_STREAM=1 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $OUT/t1 -o r --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-reference-network > $OUT/trace1.log 2>&1 || exit 1
+  MI_NO_SIDE_STREAM=1 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $OUT/t1 -o r --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-reference-network --no-secondary > $OUT/trace1.log 2>&1 || exit 1
   cp "$(find $OUT/t1 -name '*kernel_stats.csv' | head -1)" $OUT/kernel_stats.csv || exit 1
-  timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $OUT/t2 -o r --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-reference-network > $OUT/trace2.log 2>&1 || exit 1
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $OUT/t2 -o r --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-reference-network --no-secondary > $OUT/trace2.log 2>&1 || exit 1
   cp "$(find $OUT/t2 -name '*kernel_stats.csv' | head -1)" $OUT/kernel_stats_overlapped.csv || exit 1
   rm -rf $OUT/t1 $OUT/t2
   BENCH_LAYERS=1 timeout -k 10 300 python bench.py > $OUT/bench.json 2> $OUT/per_layer.txt || exit 1
