@@ -37,7 +37,8 @@ namespace {
 
 enum StepKind {
     K_IGEMM, K_WGRAD, K_NORM_FWD, K_NORM_BWD, K_C1_FWD, K_C1_T, K_C1_WGRAD, K_STENCIL, K_STENCIL_WGRAD, K_ADD,
-    K_MEMSET, K_REDUCE, K_PACK, K_KFINISH
+    K_MEMSET, K_REDUCE, K_PACK, K_KFINISH,
+    K_KFINISH_NORM      // finishing pass of a split convolution (ig) and the norm forward behind it (nm, relocated by rel_nm) in one launch
 };
 enum Base { B_ARENA, B_PARAMS, B_GRADS, B_XIN, B_LOGITS, B_DLOGITS, B_NBASE };
 
@@ -54,6 +55,7 @@ struct Step {
     IgemmParams ig; WgradParams wg; NormParams nm; C1Params c1; StencilParams stn;
     AddArgs add; MemsetArgs ms; TabArgs tab;
     std::vector<Reloc> rel;
+    std::vector<Reloc> rel_nm;   // K_KFINISH_NORM: relocations of nm (rel belongs to ig)
     double total_ms = 0; long long launches = 0;
     int wait_pack = 0;     // forward: this step is the first to read packed weights (waits for the first packing launch)
     int join_side = 0;     // forward: this step is the first to read weights of the second packing launch (joins the side stream)
@@ -73,18 +75,28 @@ struct Step {
 bool bases_ok(const Step& s, char* const* bases) {
     for (const Reloc& r : s.rel)
         if (!bases[r.base]) return false;
+    for (const Reloc& r : s.rel_nm)
+        if (!bases[r.base]) return false;
     return true;
 }
 
 template <class P>
-P resolve(const Step& s, const P& src, char* const* bases) {
+P resolve_with(const std::vector<Reloc>& rel, const P& src, char* const* bases) {
     P q = src;
-    for (const Reloc& r : s.rel) {
+    for (const Reloc& r : rel) {
         char** f = reinterpret_cast<char**>(reinterpret_cast<char*>(&q) + r.field_off);
         *f = bases[r.base] + reinterpret_cast<uintptr_t>(*f);
     }
     return q;
 }
+template <class P>
+P resolve(const Step& s, const P& src, char* const* bases) { return resolve_with(s.rel, src, bases); }
+
+#define REL_TO(vec, ps, field, base, off)                                                            \
+    do {                                                                                              \
+        (ps).field = (decltype((ps).field))(uintptr_t)(off);                                          \
+        (vec).push_back(Reloc{offsetof(std::remove_reference<decltype(ps)>::type, field), base});     \
+    } while (0)
 
 struct Ten {  // a channels-last tensor inside the arena
     size_t off = 0; int pitch = 0; int coff = 0; int base = B_ARENA;
@@ -315,18 +327,47 @@ struct Builder {
 
     void add_norm_fwd(const std::string& layer, int res, int c, int dt, const Ten& raw, size_t stats_off,
                       const std::string& alpha, const Ten* resid, const Ten& out, int lid) {
-        Step& s = push(u.fwd, K_NORM_FWD, layer);
+        // A contraction-split convolution of a small image that produced `raw` a step or three ago: its finishing
+        // pass takes the norm with it (one launch instead of two).  With a residual operand the finishing pass must be
+        // the last step, so that nothing between it and here can be the residual's producer, and must not have a second
+        // destination (the residual half of a fused two-output convolution is written by other workgroups of that launch).
+        Step* fin = nullptr;
+        for (size_t back = 1; back <= 3 && back <= u.fwd.size(); ++back) {
+            Step& t = u.fwd[u.fwd.size() - back];
+            if (t.kind != K_KFINISH || back == u.fwd.size()) continue;
+            const Step& cv = u.fwd[u.fwd.size() - back - 1];
+            if (cv.kind != K_IGEMM || cv.ig.kpart != t.ig.kpart) continue;
+            if (raw.base == B_ARENA && (size_t)(uintptr_t)t.ig.out == raw.off && t.ig.out_pitch == raw.pitch && t.ig.out_coff == raw.coff &&
+                (size_t)(uintptr_t)t.ig.stats == stats_off && t.dtype == dt && (!resid || (back == 1 && !t.ig.out1)) &&
+                finish_norm_ok(t.ig, c, (int)u.rp[res])) {
+                fin = &t;
+                break;
+            }
+        }
+        Step& s = fin ? *fin : push(u.fwd, K_NORM_FWD, layer);
+        std::vector<Reloc>& rel = fin ? s.rel_nm : s.rel;
         s.dtype = dt;
         NormParams& p = s.nm;
-        REL(s, p, x, raw.base, raw.off); p.x_pitch = raw.pitch; p.x_coff = raw.coff;
-        if (resid) { REL(s, p, res, resid->base, resid->off); p.res_pitch = resid->pitch; p.res_coff = resid->coff; }
-        REL(s, p, out, out.base, out.off); p.out_pitch = out.pitch; p.out_coff = out.coff;
-        REL(s, p, stats, B_ARENA, stats_off);
-        REL(s, p, alpha, B_PARAMS, poff(alpha) * sizeof(float));
+        REL_TO(rel, p, x, raw.base, raw.off); p.x_pitch = raw.pitch; p.x_coff = raw.coff;
+        if (resid) { REL_TO(rel, p, res, resid->base, resid->off); p.res_pitch = resid->pitch; p.res_coff = resid->coff; }
+        REL_TO(rel, p, out, out.base, out.off); p.out_pitch = out.pitch; p.out_coff = out.coff;
+        REL_TO(rel, p, stats, B_ARENA, stats_off);
+        REL_TO(rel, p, alpha, B_PARAMS, poff(alpha) * sizeof(float));
         p.nb = u.nb; p.npix = (int)u.rp[res]; p.c = c; p.eps = 1e-5f; p.layer = (unsigned)lid;
         const int esz = dt ? 2 : 4;
-        s.kernel = c == 1 ? "norm1_fwd_kernel" : (dt ? "norm_fwd_kernel<BF16>" : "norm_fwd_kernel<F32>");
-        s.work = (double)u.nb * u.rp[res] * c * esz * (resid ? 3.0 : 2.0);
+        const double nbytes = (double)u.nb * u.rp[res] * c * esz * (resid ? 3.0 : 2.0);
+        if (fin) {
+            // the convolution in front of its finishing pass writes the partial sums in the layout this launch reads
+            Step& conv = *(fin - 1);
+            conv.ig.kpart_blocked = 1; s.ig.kpart_blocked = 1;
+            s.kind = K_KFINISH_NORM;
+            s.layer += " + " + layer.substr(layer.rfind(' ') == std::string::npos ? 0 : layer.rfind(' ') + 1);
+            s.kernel = dt ? "finish_norm_kernel<BF16>" : "finish_norm_kernel<F32>";
+            s.bytes += nbytes;
+        } else {
+            s.kernel = c == 1 ? "norm1_fwd_kernel" : (dt ? "norm_fwd_kernel<BF16>" : "norm_fwd_kernel<F32>");
+            s.work = nbytes;
+        }
         record_norm(res, c, dt, raw, stats_off, lid);
     }
     void record_norm(int res, int c, int dt, const Ten& raw, size_t stats_off, int lid) {
@@ -338,24 +379,49 @@ struct Builder {
 
     void add_norm_bwd(const std::string& layer, int res, int c, int dt, const Ten& dy, const Ten& raw, size_t stats_off,
                       const std::string& alpha, const Ten& dx, int lid) {
-        Step& s = push(u.bwd, K_NORM_BWD, layer);
+        // A contraction-split data-gradient convolution of a small image that produced `dy` a few steps ago (a weight
+        // gradient or a gradient reduction may sit in between): its finishing pass takes this norm backward with it.
+        Step* fin = nullptr;
+        for (size_t back = 1; back <= 4 && back < u.bwd.size(); ++back) {
+            Step& t = u.bwd[u.bwd.size() - back];
+            if (t.kind == K_WGRAD || t.kind == K_C1_WGRAD || t.kind == K_STENCIL_WGRAD || t.kind == K_REDUCE) continue;
+            if (t.kind != K_KFINISH) break;          // any other step may be the one that completes dy
+            const Step& cv = u.bwd[u.bwd.size() - back - 1];
+            if (cv.kind == K_IGEMM && cv.ig.kpart == t.ig.kpart && dy.base == B_ARENA && (size_t)(uintptr_t)t.ig.out == dy.off &&
+                t.ig.out_pitch == dy.pitch && t.ig.out_coff == dy.coff && t.dtype == dt &&
+                finish_norm_bwd_ok(t.ig, dt, c, (int)u.rp[res], u.nb))
+                fin = &t;
+            break;
+        }
+        Step& s = fin ? *fin : push(u.bwd, K_NORM_BWD, layer);
+        std::vector<Reloc>& rel = fin ? s.rel_nm : s.rel;
         s.dtype = dt;
         NormParams& p = s.nm;
-        REL(s, p, x, raw.base, raw.off); p.x_pitch = raw.pitch; p.x_coff = raw.coff;
-        REL(s, p, dy, dy.base, dy.off); p.dy_pitch = dy.pitch; p.dy_coff = dy.coff;
-        REL(s, p, out, dx.base, dx.off); p.out_pitch = dx.pitch; p.out_coff = dx.coff;
-        REL(s, p, stats, B_ARENA, stats_off);
+        REL_TO(rel, p, x, raw.base, raw.off); p.x_pitch = raw.pitch; p.x_coff = raw.coff;
+        REL_TO(rel, p, dy, dy.base, dy.off); p.dy_pitch = dy.pitch; p.dy_coff = dy.coff;
+        REL_TO(rel, p, out, dx.base, dx.off); p.out_pitch = dx.pitch; p.out_coff = dx.coff;
+        REL_TO(rel, p, stats, B_ARENA, stats_off);
         const size_t bs = bstats_alloc((size_t)u.nb * MI_NSLOT * c * 2 * sizeof(double));
         const int nda = u.nb * norm_bwd_reduce_blocks((int)u.rp[res], c);   // one slope-gradient partial per workgroup
         const size_t da = bstats_alloc((size_t)nda * sizeof(float));
-        REL(s, p, bstats, B_ARENA, bs);
-        REL(s, p, dalpha, B_ARENA, da);
+        REL_TO(rel, p, bstats, B_ARENA, bs);
+        REL_TO(rel, p, dalpha, B_ARENA, da);
         p.dalpha_slots = 1;
-        REL(s, p, alpha, B_PARAMS, poff(alpha) * sizeof(float));
+        REL_TO(rel, p, alpha, B_PARAMS, poff(alpha) * sizeof(float));
         p.nb = u.nb; p.npix = (int)u.rp[res]; p.c = c; p.eps = 1e-5f; p.layer = (unsigned)lid;
         const int esz = dt ? 2 : 4;
-        s.kernel = c == 1 ? "norm1_bwd_kernels" : (dt ? "norm_bwd_kernels<BF16>" : "norm_bwd_kernels<F32>");
-        s.work = (double)u.nb * u.rp[res] * c * esz * 3.0;   // algorithmic: x and dy read, dx written (the kernels read x and dy twice)
+        const double nbytes = (double)u.nb * u.rp[res] * c * esz * 3.0;   // algorithmic: x and dy read, dx written (the kernels read x and dy twice)
+        if (fin) {
+            Step& conv = *(fin - 1);
+            conv.ig.kpart_blocked = 1; s.ig.kpart_blocked = 1;
+            s.kind = K_KFINISH_NORM;
+            s.layer += " + " + layer.substr(layer.find(' ') == std::string::npos ? 0 : layer.find(' ') + 1);
+            s.kernel = dt ? "finish_norm_bwd_kernel<BF16>" : "finish_norm_bwd_kernel<F32>";
+            s.bytes += nbytes;
+        } else {
+            s.kernel = c == 1 ? "norm1_bwd_kernels" : (dt ? "norm_bwd_kernels<BF16>" : "norm_bwd_kernels<F32>");
+            s.work = nbytes;
+        }
         add_scalar_reduce(da, nda, alpha);
     }
 
@@ -1018,6 +1084,13 @@ int run_step(mi_unet& u, Step& s, char* const* bases, int training, uint64_t see
     switch (s.kind) {
         case K_IGEMM: return launch_igemm(s.dtype, resolve(s, s.ig, bases), st);
         case K_KFINISH: return launch_ksplit_finish(s.dtype, resolve(s, s.ig, bases), st);
+        case K_KFINISH_NORM: {
+            NormParams p = resolve_with(s.rel_nm, s.nm, bases);
+            p.seed = seed;
+            norm_set_dropout(p, training ? u.cfg.dropout : 0.f);
+            return p.dy ? launch_finish_norm_bwd(s.dtype, resolve(s, s.ig, bases), p, st)
+                        : launch_finish_norm(s.dtype, resolve(s, s.ig, bases), p, st);
+        }
         case K_WGRAD: return launch_wgrad(s.dtype, resolve(s, s.wg, bases), st);
         case K_NORM_FWD:
         case K_NORM_BWD: {
@@ -1316,6 +1389,7 @@ int64_t mi_unet_step_output_offset(const mi_unet* u, int backward, int i) {
     switch (s.kind) {
         case K_IGEMM: return arena_field(offsetof(IgemmParams, out)) ? (int64_t)(uintptr_t)s.ig.out : -1;
         case K_NORM_FWD: case K_NORM_BWD: return arena_field(offsetof(NormParams, out)) ? (int64_t)(uintptr_t)s.nm.out : -1;
+        case K_KFINISH_NORM: return (int64_t)(uintptr_t)s.nm.out;
         case K_C1_FWD: return arena_field(offsetof(C1Params, y_out)) ? (int64_t)(uintptr_t)s.c1.y_out : -1;
         case K_C1_T: return arena_field(offsetof(C1Params, x1_out)) ? (int64_t)(uintptr_t)s.c1.x1_out : -1;
         case K_STENCIL: return arena_field(offsetof(StencilParams, out)) ? (int64_t)(uintptr_t)s.stn.out : -1;
@@ -1332,6 +1406,7 @@ int64_t mi_unet_step_aux_offset(const mi_unet* u, int backward, int i) {
     if (i < 0 || i >= (int)l.size()) return -1;
     const Step& s = l[i];
     if (s.kind == K_NORM_BWD) return (int64_t)(uintptr_t)s.nm.bstats;
+    if (s.kind == K_KFINISH_NORM) return (int64_t)(uintptr_t)(backward ? (const void*)s.nm.bstats : (const void*)s.nm.stats);
     if (s.kind == K_NORM_FWD) return (int64_t)(uintptr_t)s.nm.stats;
     return -1;
 }

@@ -82,11 +82,24 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, v4f (&acc)[
                       ox = bx * p.so + p.phase_off[ph][2];
             const size_t op = ((size_t)(img * p.od[0] + oz) * p.od[1] + oy) * p.od[2] + ox;
             const size_t npo = (size_t)p.nb * p.od[0] * p.od[1] * p.od[2];
-            float* dst = p.kpart + ((size_t)ksp * npo + op) * p.N + n0;
+            if (p.kpart_blocked) {
+                // [split][image][N / 8][pixel of the image][8]: the reader owns one image and eight channels
+                const size_t npi = (size_t)p.od[0] * p.od[1] * p.od[2];
+                const size_t pin = ((size_t)oz * p.od[1] + oy) * p.od[2] + ox;
+                float* dst = p.kpart + (((size_t)ksp * p.nb + img) * (p.N / 8)) * npi * 8 + pin * 8;
 #pragma unroll
-            for (int nf = 0; nf < NFRAG; ++nf) {
-                const int tc = chan_of_row<NFRAG>(nf, 4 * g);     // four consecutive channels
-                *reinterpret_cast<float4*>(dst + tc) = make_float4(acc[mf][nf][0], acc[mf][nf][1], acc[mf][nf][2], acc[mf][nf][3]);
+                for (int nf = 0; nf < NFRAG; ++nf) {
+                    const int c = n0 + chan_of_row<NFRAG>(nf, 4 * g);
+                    *reinterpret_cast<float4*>(dst + (size_t)(c >> 3) * npi * 8 + (c & 7)) =
+                        make_float4(acc[mf][nf][0], acc[mf][nf][1], acc[mf][nf][2], acc[mf][nf][3]);
+                }
+            } else {
+                float* dst = p.kpart + ((size_t)ksp * npo + op) * p.N + n0;
+#pragma unroll
+                for (int nf = 0; nf < NFRAG; ++nf) {
+                    const int tc = chan_of_row<NFRAG>(nf, 4 * g);     // four consecutive channels
+                    *reinterpret_cast<float4*>(dst + tc) = make_float4(acc[mf][nf][0], acc[mf][nf][1], acc[mf][nf][2], acc[mf][nf][3]);
+                }
             }
         } else if (valid) {
             const int oz = bz * p.so + p.phase_off[ph][0], oy = by * p.so + p.phase_off[ph][1],

@@ -1194,6 +1194,7 @@ void igemm_parallelism(int dtype, const IgemmParams& p, long long* wgs, int* nkc
 int launch_ksplit_finish(int dtype, const IgemmParams& pin, hipStream_t st) {
     IgemmParams p = pin;
     if (!p.out1) p.out0_c = p.N;
+    MI_CHECK(!p.kpart_blocked, "blocked partial sums are read by the finish + norm launch");
     const int npix_img = p.od[0] * p.od[1] * p.od[2];
     const int rows = 256 / (p.N / 4);
     int gx = (npix_img + rows * 4 - 1) / (rows * 4);

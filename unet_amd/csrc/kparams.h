@@ -37,6 +37,8 @@ struct IgemmParams {
     unsigned mg_pd2, mg_pd12;               // reciprocals of pd[2] and pd[1]*pd[2], filled in by the launcher
     int ksplit; float* kpart;               // > 1: the contraction chunks are split over ksplit workgroups that write raw fp32
                                             // partial sums [ksplit][output pixel][N] to kpart; launch_ksplit_finish completes the layer
+    int kpart_blocked;                      // partial sums as [ksplit][image][N / 8][pixel of the image][8] instead: the layout
+                                            // launch_finish_norm reads (a workgroup there owns one image and eight channels)
     int tpw;                                // 2-D specialisation: consecutive tiles per workgroup, filled in by the launcher
 };
 
@@ -174,6 +176,10 @@ void wgrad_choose_split(int dtype, WgradParams& p, int target = 0);   // target:
 int launch_pack_one(int dtype, const PackDesc& d, hipStream_t st);
 int launch_norm_fwd(int dtype, const NormParams& p, hipStream_t st);
 int launch_norm_bwd(int dtype, const NormParams& p, hipStream_t st);
+bool finish_norm_ok(const IgemmParams& ip, int c, int npix);   // norm.hip: one launch can finish the split layer `ip` and normalise its output
+int launch_finish_norm(int dtype, const IgemmParams& ip, const NormParams& p, hipStream_t st);
+bool finish_norm_bwd_ok(const IgemmParams& ip, int dtype, int c, int npix, int nb);   // the same for a split data gradient in front of a norm backward
+int launch_finish_norm_bwd(int dtype, const IgemmParams& ip, const NormParams& p, hipStream_t st);
 int norm_bwd_reduce_blocks(int npix, int c);   // workgroups per image of the backward reduction
 int launch_c1_s2_fwd(int dtype, const C1Params& p, hipStream_t st);
 int launch_c1_s2_T(int dtype, const C1Params& p, hipStream_t st);

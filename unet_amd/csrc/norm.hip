@@ -339,25 +339,86 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const NormParams p)
         unit(*reinterpret_cast<const uint4*>(xb + ((unsigned)pix0 * xs + cb)), *reinterpret_cast<const uint4*>(gb + ((unsigned)pix0 * gs + cb)), pix0);
 }
 
-// Backward in ONE launch for small images: a workgroup owns one image and NORM_SMALL_CG channels, keeps its share of
-// x and dy in registers between the reduction and the apply step (at most NORM_SMALL_K sweeps of 256 / (vectors per
-// pixel of the group) pixels), reduces inside the workgroup (no global accumulators, no second pass over memory) and
-// writes dx.  For tensors of a few hundred kilobytes the two-kernel form is two dependent launches of a few
-// microseconds each with nothing to do; at the sizes of a large batch it loses (32 bytes per pixel and workgroup is a
-// poor access shape), so the launcher takes it only for small tensors.  Same arithmetic per element as the pair.
-constexpr int NORM_SMALL_CG = 16;
-constexpr int NORM_SMALL_K = 16;
-template <class TR, bool DROP>
-__global__ __launch_bounds__(256) void norm_bwd_small_kernel(const NormParams p) {
+// ---- small images: one workgroup per (image, eight channels) -----------------------------------------------------------
+// For tensors of a few hundred kilobytes the streaming kernels are dependent launches of a few microseconds each with
+// nothing to do.  The kernels below give a workgroup of T threads one image and SM_CG channels; a thread keeps its
+// pixels (at most SmKeep sweeps of the workgroup over the image) in registers, so every reduction over the image stays
+// inside the workgroup: no global accumulators, no second pass over memory.  At the sizes of a large batch they lose
+// (32 bytes per pixel and workgroup is a poor access shape), so the launchers take them only for small tensors.
+constexpr int SM_CG = 8;
+template <class TR> struct SmKeep { static constexpr int K = TR::ESZ == 2 ? 2 : 4; };
+
+// v[VEC] = sum over the shares of a contraction-split convolution, in share order.  The shares sit `stride` floats
+// apart; all KS loads are issued before the first use, shares past the last one (index ksl) re-read it and add nothing.
+template <int VEC, int KS>
+__device__ __forceinline__ void sum_shares(const float* q, size_t stride, int ksl, float* v) {
+    float4 t[KS][VEC / 4];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int g = 0; g < VEC / 4; ++g)
+            t[ks][g] = *reinterpret_cast<const float4*>(q + (ks < ksl ? ks : ksl) * stride + 4 * g);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const float m = ks <= ksl ? 1.f : 0.f;
+#pragma unroll
+        for (int g = 0; g < VEC / 4; ++g) {
+            v[4 * g] += m * t[ks][g].x; v[4 * g + 1] += m * t[ks][g].y;
+            v[4 * g + 2] += m * t[ks][g].z; v[4 * g + 3] += m * t[ks][g].w;
+        }
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void sum_shares_any(const float* q, size_t stride, int ksl, float* v) {
+    if (ksl < 2) sum_shares<VEC, 2>(q, stride, ksl, v);
+    else if (ksl < 4) sum_shares<VEC, 4>(q, stride, ksl, v);
+    else sum_shares<VEC, 8>(q, stride, ksl, v);
+}
+
+// Folds s[W] over the pixel rows of the workgroup (lanes of one channel vector sit CVW apart inside a wave, the waves
+// meet in LDS in wave order); after the barrier part[0][cv][e] holds the totals.
+template <int W, int CVW, int NW>
+__device__ __forceinline__ void fold_rows(float* s, float (&part)[NW][CVW][W]) {
+#pragma unroll
+    for (int e = 0; e < W; ++e) {
+        float t = s[e];
+#pragma unroll
+        for (int o = 32; o >= CVW; o >>= 1) t += __shfl_xor(t, o, 64);
+        s[e] = t;
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane < CVW) {
+#pragma unroll
+        for (int e = 0; e < W; ++e) part[w][lane][e] = s[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < CVW * W) {
+        const int vcv = threadIdx.x / W, ve = threadIdx.x % W;
+        float t = part[0][vcv][ve];
+#pragma unroll
+        for (int ww = 1; ww < NW; ++ww) t += part[ww][vcv][ve];
+        part[0][vcv][ve] = t;
+    }
+    __syncthreads();
+}
+
+// Norm backward in ONE launch.  PARTS: dy is not read from a tensor but completed here from the partial sums of the
+// contraction-split data-gradient convolution in front of this norm (shares [split][image][N / 8][pixel][8], plus its
+// addend), rounded and stored to that convolution's destination on the way: the finishing pass of that layer.
+// Same arithmetic per element as the two streaming kernels.
+template <class TR, bool DROP, int T, bool PARTS>
+__global__ __launch_bounds__(T) void norm_bwd_small_kernel(const NormParams p, const IgemmParams ip) {
     constexpr int VEC = TR::VEC, ESZ = TR::ESZ;
-    constexpr int CVW = NORM_SMALL_CG / VEC;      // 16-byte vectors per pixel of the channel group (2 or 4)
-    constexpr int ROWS = 256 / CVW;               // pixels per sweep
-    __shared__ float mom[NORM_SMALL_CG * 2];
-    __shared__ float part[256 * 2 * VEC];
-    __shared__ float red_da[4];
+    constexpr int CVW = SM_CG / VEC, ROWS = T / CVW, NW = T / 64, KEEP = SmKeep<TR>::K;
+    __shared__ float mom[SM_CG * 2];
+    __shared__ float part[NW][CVW][2 * VEC];
+    __shared__ float red_da[NW];
     const int img = blockIdx.y;
-    const int c0 = blockIdx.x * NORM_SMALL_CG;
-    if (threadIdx.x < NORM_SMALL_CG) {
+    const int c0 = blockIdx.x * SM_CG;
+    const int npix = p.npix;
+    if (threadIdx.x < SM_CG) {
         const int ch = c0 + threadIdx.x;
         double s1 = 0.0, s2 = 0.0;
 #pragma unroll
@@ -365,28 +426,56 @@ __global__ __launch_bounds__(256) void norm_bwd_small_kernel(const NormParams p)
             const double* q = p.stats + (((size_t)img * MI_NSLOT + sl) * p.c + ch) * 2;
             s1 += q[0]; s2 += q[1];
         }
-        const double mean = s1 / (double)p.npix;
-        double var = s2 / (double)p.npix - mean * mean;
+        const double mean = s1 / (double)npix;
+        double var = s2 / (double)npix - mean * mean;
         var = var > 0.0 ? var : 0.0;
         mom[threadIdx.x * 2] = (float)mean;
         mom[threadIdx.x * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
     }
     const int cv = threadIdx.x % CVW, prow = threadIdx.x / CVW;
     const int ch0 = c0 + cv * VEC;
-    const size_t img_pix = (size_t)img * p.npix;
-    const char* xb = p.x + (img_pix * p.x_pitch + p.x_coff) * ESZ;
-    const char* gb = p.dy + (img_pix * p.dy_pitch + p.dy_coff) * ESZ;
-    char* ob = p.out + (img_pix * p.out_pitch + p.out_coff) * ESZ;
-    const unsigned xs = p.x_pitch * ESZ, gs = p.dy_pitch * ESZ, os = p.out_pitch * ESZ, cb = ch0 * ESZ;
-    // every load of the image share is issued before the first use
-    uint4 xr[NORM_SMALL_K], gr[NORM_SMALL_K];
+    const size_t img_pix = (size_t)img * npix;
+    const char* xb = p.x + (img_pix * p.x_pitch + p.x_coff + ch0) * ESZ;
+    char* ob = p.out + (img_pix * p.out_pitch + p.out_coff + ch0) * ESZ;
+    const unsigned xs = p.x_pitch * ESZ, os = p.out_pitch * ESZ;
+    uint4 xr[KEEP], gr[KEEP];
 #pragma unroll
-    for (int k = 0; k < NORM_SMALL_K; ++k) {
+    for (int k = 0; k < KEEP; ++k) {
         const int pix = prow + k * ROWS;
-        xr[k] = make_uint4(0u, 0u, 0u, 0u); gr[k] = xr[k];
-        if (pix < p.npix) {
-            xr[k] = *reinterpret_cast<const uint4*>(xb + ((unsigned)pix * xs + cb));
-            gr[k] = *reinterpret_cast<const uint4*>(gb + ((unsigned)pix * gs + cb));
+        xr[k] = *reinterpret_cast<const uint4*>(xb + (unsigned)(pix < npix ? pix : npix - 1) * xs);
+    }
+    if (PARTS) {
+        const float* kp = ip.kpart + ((size_t)img * (ip.N / SM_CG) + blockIdx.x) * (size_t)npix * SM_CG + cv * VEC;
+        const size_t stride = (size_t)ip.nb * npix * ip.N;
+        const int ksl = ip.ksplit - 1;
+        const char* ab = ip.addend ? ip.addend + (img_pix * ip.add_pitch + ip.add_coff + ch0) * ESZ : nullptr;
+        char* db = ip.out + (img_pix * ip.out_pitch + ip.out_coff + ch0) * ESZ;
+        const unsigned as = ip.add_pitch * ESZ, ds = ip.out_pitch * ESZ;
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) {
+            const int pix = prow + k * ROWS;
+            const int pc = pix < npix ? pix : npix - 1;
+            uint4 ar = make_uint4(0u, 0u, 0u, 0u);
+            if (ab) ar = *reinterpret_cast<const uint4*>(ab + (unsigned)pc * as);
+            float v[VEC];
+            sum_shares_any<VEC>(kp + (size_t)pc * SM_CG, stride, ksl, v);
+            if (ab) {
+                float a[VEC];
+                unpack_vec<TR>(ar, a);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[e] += a[e];
+            }
+            gr[k] = pack_vec<TR>(v);
+            if (pix < npix) *reinterpret_cast<uint4*>(db + (unsigned)pix * ds) = gr[k];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        const char* gb = p.dy + (img_pix * p.dy_pitch + p.dy_coff + ch0) * ESZ;
+        const unsigned gs = p.dy_pitch * ESZ;
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) {
+            const int pix = prow + k * ROWS;
+            gr[k] = *reinterpret_cast<const uint4*>(gb + (unsigned)(pix < npix ? pix : npix - 1) * gs);
         }
     }
     __syncthreads();
@@ -401,9 +490,9 @@ __global__ __launch_bounds__(256) void norm_bwd_small_kernel(const NormParams p)
 #pragma unroll
     for (int e = 0; e < 2 * VEC; ++e) s12[e] = 0.f;
 #pragma unroll
-    for (int k = 0; k < NORM_SMALL_K; ++k) {
+    for (int k = 0; k < KEEP; ++k) {
         const int pix = prow + k * ROWS;
-        if (pix < p.npix) {
+        if (pix < npix) {
             float x[VEC], dy[VEC];
             bool keep[VEC];
             unpack_vec<TR>(xr[k], x); unpack_vec<TR>(gr[k], dy);
@@ -425,22 +514,22 @@ __global__ __launch_bounds__(256) void norm_bwd_small_kernel(const NormParams p)
     }
     da = wave_sum(da);
     if ((threadIdx.x & 63) == 0) red_da[threadIdx.x >> 6] = da;
-    NormLane l;
-    l.cv = cv; l.prow = prow; l.rows = ROWS; l.ch0 = ch0; l.pbeg = 0; l.pend = p.npix; l.active = true;
-    sum_rows<VEC>(s12, part, l, CVW);             // ends with a barrier: part[cv * 2 VEC + e] holds the totals, red_da is visible
+    fold_rows<2 * VEC, CVW, NW>(s12, part);       // its barriers make red_da visible too
     if (threadIdx.x == 0 && p.dalpha) {
-        const float v = ((red_da[0] + red_da[1]) + red_da[2]) + red_da[3];
+        float v = red_da[0];
+#pragma unroll
+        for (int ww = 1; ww < NW; ++ww) v += red_da[ww];
         if (p.dalpha_slots) p.dalpha[img * gridDim.x + blockIdx.x] = v;
         else atomicAdd(p.dalpha, v);
     }
-    const float inv_n = 1.0f / (float)p.npix;
+    const float inv_n = 1.0f / (float)npix;
     float b1[VEC], b2[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) { b1[e] = part[cv * 2 * VEC + e] * inv_n; b2[e] = part[cv * 2 * VEC + VEC + e] * inv_n; }
+    for (int e = 0; e < VEC; ++e) { b1[e] = part[0][cv][e] * inv_n; b2[e] = part[0][cv][VEC + e] * inv_n; }
 #pragma unroll
-    for (int k = 0; k < NORM_SMALL_K; ++k) {
+    for (int k = 0; k < KEEP; ++k) {
         const int pix = prow + k * ROWS;
-        if (pix < p.npix) {
+        if (pix < npix) {
             float x[VEC], dy[VEC], o[VEC];
             bool keep[VEC];
             unpack_vec<TR>(xr[k], x); unpack_vec<TR>(gr[k], dy);
@@ -457,7 +546,115 @@ __global__ __launch_bounds__(256) void norm_bwd_small_kernel(const NormParams p)
                 if (DROP) gh *= sc;
                 o[e] = rstd[e] * (gh - b1[e] - xh * b2[e]);
             }
-            store_vec<TR>(ob + ((unsigned)pix * os + cb), o);
+            store_vec<TR>(ob + (unsigned)pix * os, o);
+        }
+    }
+}
+
+// Contraction-split layers of small images: the finishing pass of the convolution and the norm forward in ONE
+// launch.  A workgroup of T threads owns one image and SM_CG output channels of the convolution; a thread keeps its
+// pixels (at most FN_KEEP sweeps of the workgroup over the image) in registers:
+//   pass 1: v[pixel][ch] = sum_split partial[split][pixel][ch] (+ bias), rounded to the activation type and stored to
+//           the convolution's destination(s); the per-channel sums of the values and their squares on the way;
+//   then (normalised channels only) the workgroup folds its sums, writes them to slot 0 of the forward statistics
+//   (the backward pass reads them there) and takes mean / rstd from them;
+//   pass 2: norm, dropout, PReLU and the residual on the kept (rounded) values, exactly as norm_fwd_kernel does.
+// Channel groups past the normalised channels (the residual half of a fused two-output convolution) stop after pass 1.
+template <class TR, bool DROP, bool RES, int T>
+__global__ __launch_bounds__(T) void finish_norm_kernel(const IgemmParams ip, const NormParams p) {
+    constexpr int VEC = TR::VEC, ESZ = TR::ESZ;
+    constexpr int CVW = SM_CG / VEC, ROWS = T / CVW, NW = T / 64, KEEP = SmKeep<TR>::K;
+    __shared__ float part[NW][CVW][2 * VEC];
+    __shared__ float mom[SM_CG * 2];
+    const int img = blockIdx.y, c0 = blockIdx.x * SM_CG;
+    const int cv = threadIdx.x % CVW, prow = threadIdx.x / CVW;
+    const int ch = c0 + cv * VEC;
+    const int npix = p.npix;
+    const size_t npo = (size_t)ip.nb * npix, img_pix = (size_t)img * npix;
+    const bool normed = c0 < ip.nstat;                       // uniform over the workgroup
+    const bool first = ch < ip.out0_c;
+    char* const rawb = first ? ip.out + (img_pix * ip.out_pitch + ip.out_coff + ch) * ESZ
+                             : ip.out1 + (img_pix * ip.out1_pitch + ip.out1_coff + ch - ip.out0_c) * ESZ;
+    const unsigned raws = (first ? ip.out_pitch : ip.out1_pitch) * ESZ;
+    float bias[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) bias[e] = (ip.bias && ch >= ip.bias_c0) ? ip.bias[ch - ip.bias_c0 + e] : 0.f;
+    float s12[2 * VEC];
+#pragma unroll
+    for (int e = 0; e < 2 * VEC; ++e) s12[e] = 0.f;
+    // partial sums [split][image][N / 8][pixel][8]: one contiguous run per (split, image, channel group)
+    const float* kp = ip.kpart + ((size_t)img * (ip.N / SM_CG) + blockIdx.x) * (size_t)npix * SM_CG + cv * VEC;
+    const size_t ksplit_stride = npo * ip.N;
+    const int ksl = ip.ksplit - 1;
+    uint4 kept[KEEP];
+#pragma unroll
+    for (int k = 0; k < KEEP; ++k) {
+        const int pix = prow + k * ROWS;
+        const bool valid = pix < npix;
+        const float* q = kp + (size_t)(valid ? pix : npix - 1) * SM_CG;
+        float v[VEC];
+        sum_shares_any<VEC>(q, ksplit_stride, ksl, v);
+        if (valid) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { s12[e] += v[e]; s12[VEC + e] += v[e] * v[e]; v[e] += bias[e]; }
+            kept[k] = pack_vec<TR>(v);
+            *reinterpret_cast<uint4*>(rawb + (unsigned)pix * raws) = kept[k];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!normed) return;
+    fold_rows<2 * VEC, CVW, NW>(s12, part);
+    if (threadIdx.x < SM_CG) {
+        const int vcv = threadIdx.x / VEC, ve = threadIdx.x % VEC;
+        const float t1 = part[0][vcv][ve], t2 = part[0][vcv][VEC + ve];
+        double* sq = ip.stats + (((size_t)img * MI_NSLOT) * ip.stats_c + c0 + threadIdx.x) * 2;
+        sq[0] = (double)t1; sq[1] = (double)t2;
+        const double mean = (double)t1 / (double)npix;
+        double var = (double)t2 / (double)npix - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        mom[threadIdx.x * 2] = (float)mean;
+        mom[threadIdx.x * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
+    }
+    const char* rb = RES ? p.res + (img_pix * p.res_pitch + p.res_coff + ch) * ESZ : nullptr;
+    const unsigned rs = p.res_pitch * ESZ, os = p.out_pitch * ESZ;
+    uint4 rr[KEEP];
+    if (RES) {
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) {
+            const int pix = prow + k * ROWS;
+            rr[k] = *reinterpret_cast<const uint4*>(rb + (unsigned)(pix < npix ? pix : npix - 1) * rs);
+        }
+    }
+    __syncthreads();
+    const float alpha = *p.alpha;
+    const DropKeys dk = dropout_keys(p.seed, p.layer, img, p.drop_thresh);
+    const unsigned cq = p.c / 4, gq = ch / 4;
+    const float scale = p.drop_scale;
+    float mean[VEC], rstd[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { mean[e] = mom[(cv * VEC + e) * 2]; rstd[e] = mom[(cv * VEC + e) * 2 + 1]; }
+    char* ob = p.out + (img_pix * p.out_pitch + p.out_coff + ch) * ESZ;
+#pragma unroll
+    for (int k = 0; k < KEEP; ++k) {
+        const int pix = prow + k * ROWS;
+        if (pix < npix) {
+            float x[VEC], r[VEC], o[VEC];
+            bool keep[VEC];
+            unpack_vec<TR>(kept[k], x);
+            if (RES) unpack_vec<TR>(rr[k], r);
+            if (DROP) {
+#pragma unroll
+                for (int q = 0; q < VEC / 4; ++q) dropout_keep4(dk, (unsigned)pix * cq + gq + q, keep + 4 * q);
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float d = (x[e] - mean[e]) * rstd[e];
+                if (DROP) d = keep[e] ? d * scale : 0.f;
+                float y = d > 0.f ? d : alpha * d;
+                if (RES) y += r[e];
+                o[e] = y;
+            }
+            store_vec<TR>(ob + (unsigned)pix * os, o);
         }
     }
 }
@@ -622,8 +819,8 @@ static int norm_blocks(int npix, int c, int vec, int sweeps, int cap) {
 // 2^21: at the sizes of a large batch the two streaming kernels are faster; 0 switches the kernel off).
 static bool norm_bwd_small_ok(int dtype, const NormParams& p) {
     static const long long max_elems = getenv("MI_NORM_BWD_SMALL_MAX") ? atoll(getenv("MI_NORM_BWD_SMALL_MAX")) : (1ll << 21);
-    const int rows = 256 / (NORM_SMALL_CG / (dtype ? 8 : 4));
-    return p.c >= NORM_SMALL_CG && p.c % NORM_SMALL_CG == 0 && p.npix <= rows * NORM_SMALL_K && (long long)p.nb * p.npix * p.c <= max_elems;
+    (void)dtype;
+    return p.c % SM_CG == 0 && p.npix <= 2048 && (long long)p.nb * p.npix * p.c <= max_elems;
 }
 
 // workgroups per image of the backward reduction pass
@@ -643,7 +840,7 @@ static int norm_bwd_reduce_grid(int npix, int c) {
 // partials to the first slots and leaves the rest alone): the larger of the two kernels' workgroup counts
 int norm_bwd_reduce_blocks(int npix, int c) {
     const int g = norm_bwd_reduce_grid(npix, c);
-    const int gs = (c >= NORM_SMALL_CG && c % NORM_SMALL_CG == 0) ? c / NORM_SMALL_CG : 0;
+    const int gs = c % SM_CG == 0 ? c / SM_CG : 0;
     return g > gs ? g : gs;
 }
 
@@ -694,6 +891,88 @@ int launch_norm_fwd(int dtype, const NormParams& p, hipStream_t st) {
     return check_launch("norm_fwd");
 }
 
+// Finishing pass of a contraction-split convolution and the norm forward behind it as one launch: small images only
+// (a workgroup walks a whole image), convolutions without an addend whose statistics cover exactly the normalised
+// channels.  MI_NO_FINISH_NORM=1 keeps the two launches.
+bool finish_norm_ok(const IgemmParams& ip, int c, int npix) {
+    static const bool off = getenv("MI_NO_FINISH_NORM") != nullptr;
+    if (off || ip.ksplit < 2 || ip.ksplit > 8 || ip.addend || !ip.stats) return false;
+    if (ip.N % SM_CG || c % SM_CG || ip.nstat != c || ip.stats_c != c) return false;
+    if (ip.out1 && (ip.out0_c % SM_CG || ip.out0_c != c)) return false;
+    if (!ip.out1 && ip.N != c) return false;
+    return npix <= 2048 && npix == ip.od[0] * ip.od[1] * ip.od[2];      // FN_KEEP sweeps of 1024 threads
+}
+
+int launch_finish_norm(int dtype, const IgemmParams& pin, const NormParams& p, hipStream_t st) {
+    IgemmParams ip = pin;
+    if (!ip.out1) ip.out0_c = ip.N;
+    MI_CHECK(finish_norm_ok(pin, p.c, p.npix) && pin.kpart_blocked, "finish + norm launch on a layer it does not serve");
+    {
+        long long pm = ip.out_pitch > p.out_pitch ? ip.out_pitch : p.out_pitch;
+        if (ip.out1 && ip.out1_pitch > pm) pm = ip.out1_pitch;
+        if (p.res && p.res_pitch > pm) pm = p.res_pitch;
+        MI_CHECK((long long)p.npix * pm * (dtype ? 2 : 4) < (1ll << 32), "one image of a tensor must stay below 4 GiB");
+    }
+    const dim3 grid(ip.N / SM_CG, ip.nb);
+    const bool small = p.npix <= 512;       // FN_KEEP sweeps of 256 threads cover the image
+#define FN_CASE(TR, D, R)                                                                                   \
+    do {                                                                                                    \
+        if (small) hipLaunchKernelGGL((finish_norm_kernel<TR, D, R, 256>), grid, dim3(256), 0, st, ip, p);   \
+        else hipLaunchKernelGGL((finish_norm_kernel<TR, D, R, 1024>), grid, dim3(1024), 0, st, ip, p);       \
+    } while (0)
+    const bool drop = p.drop_thresh != 0, res = p.res != nullptr;
+    if (dtype) {
+        if (drop) { if (res) FN_CASE(BF16, true, true); else FN_CASE(BF16, true, false); }
+        else { if (res) FN_CASE(BF16, false, true); else FN_CASE(BF16, false, false); }
+    } else {
+        if (drop) { if (res) FN_CASE(F32, true, true); else FN_CASE(F32, true, false); }
+        else { if (res) FN_CASE(F32, false, true); else FN_CASE(F32, false, false); }
+    }
+#undef FN_CASE
+    return check_launch("finish_norm");
+}
+
+// One-launch norm backward of a small tensor; with `ip` the gradient dy is completed here from the partial sums of the
+// contraction-split convolution `ip` (see norm_bwd_small_kernel).
+static int launch_norm_bwd_small(int dtype, const NormParams& p, const IgemmParams* ip, hipStream_t st) {
+    IgemmParams q = IgemmParams();
+    if (ip) q = *ip;
+    const dim3 grid(p.c / SM_CG, p.nb);
+    const bool drop = p.drop_thresh != 0, small = p.npix <= 512, parts = ip != nullptr;
+#define NBS_CASE(TR, D)                                                                                                  \
+    do {                                                                                                                 \
+        if (small) { if (parts) hipLaunchKernelGGL((norm_bwd_small_kernel<TR, D, 256, true>), grid, dim3(256), 0, st, p, q);     \
+                     else hipLaunchKernelGGL((norm_bwd_small_kernel<TR, D, 256, false>), grid, dim3(256), 0, st, p, q); }        \
+        else { if (parts) hipLaunchKernelGGL((norm_bwd_small_kernel<TR, D, 1024, true>), grid, dim3(1024), 0, st, p, q);         \
+               else hipLaunchKernelGGL((norm_bwd_small_kernel<TR, D, 1024, false>), grid, dim3(1024), 0, st, p, q); }            \
+    } while (0)
+    if (dtype) { if (drop) NBS_CASE(BF16, true); else NBS_CASE(BF16, false); }
+    else { if (drop) NBS_CASE(F32, true); else NBS_CASE(F32, false); }
+#undef NBS_CASE
+    return check_launch(parts ? "finish_norm_bwd" : "norm_bwd_small");
+}
+
+// A contraction-split data-gradient convolution whose output is the dy of a small norm backward: one launch finishes
+// the convolution (shares + addend -> dy, stored) and runs the norm backward.  MI_NO_FINISH_NORM=1 keeps two launches.
+bool finish_norm_bwd_ok(const IgemmParams& ip, int dtype, int c, int npix, int nb) {
+    static const bool off = getenv("MI_NO_FINISH_NORM") != nullptr;
+    if (off || ip.ksplit < 2 || ip.ksplit > 8 || ip.stats || ip.bias || ip.out1) return false;
+    if (ip.N != c || c % SM_CG || npix != ip.od[0] * ip.od[1] * ip.od[2] || nb != ip.nb) return false;
+    NormParams t = NormParams(); t.c = c; t.npix = npix; t.nb = nb;
+    return norm_bwd_small_ok(dtype, t);
+}
+int launch_finish_norm_bwd(int dtype, const IgemmParams& ip, const NormParams& p, hipStream_t st) {
+    MI_CHECK(finish_norm_bwd_ok(ip, dtype, p.c, p.npix, p.nb) && ip.kpart_blocked, "finish + norm backward launch on a layer it does not serve");
+    {
+        long long pm = p.x_pitch > p.out_pitch ? p.x_pitch : p.out_pitch;
+        if (ip.out_pitch > pm) pm = ip.out_pitch;
+        if (ip.addend && ip.add_pitch > pm) pm = ip.add_pitch;
+        MI_CHECK((long long)p.npix * pm * (dtype ? 2 : 4) < (1ll << 32), "one image of a tensor must stay below 4 GiB");
+    }
+    MI_CHECK(!p.drop_thresh || (long long)p.npix * p.c < (1ll << 34), "dropout numbers the elements of one image in 34 bits");
+    return launch_norm_bwd_small(dtype, p, &ip, st);
+}
+
 // bstats ([nb][NSLOT][c][2] doubles) must be zero on entry; dalpha is accumulated into.
 int launch_norm_bwd(int dtype, const NormParams& p, hipStream_t st) {
     {
@@ -715,17 +994,7 @@ int launch_norm_bwd(int dtype, const NormParams& p, hipStream_t st) {
     MI_CHECK(p.c % vec == 0, "channels must be a multiple of the 16-byte vector");
     MI_CHECK(p.c / vec <= 256, "too many channels for the reduction kernel");
     const bool drop = p.drop_thresh != 0;
-    if (norm_bwd_small_ok(dtype, p)) {
-        const dim3 gs(p.c / NORM_SMALL_CG, p.nb);
-        if (dtype) {
-            if (drop) hipLaunchKernelGGL((norm_bwd_small_kernel<BF16, true>), gs, dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((norm_bwd_small_kernel<BF16, false>), gs, dim3(256), 0, st, p);
-        } else {
-            if (drop) hipLaunchKernelGGL((norm_bwd_small_kernel<F32, true>), gs, dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((norm_bwd_small_kernel<F32, false>), gs, dim3(256), 0, st, p);
-        }
-        return check_launch("norm_bwd_small");
-    }
+    if (norm_bwd_small_ok(dtype, p)) return launch_norm_bwd_small(dtype, p, nullptr, st);
     const size_t lds = (size_t)p.c * 4 * sizeof(float);
     const size_t lds_r = ((size_t)p.c * 2 + 256 * 2 * vec) * sizeof(float);
     const int gr = norm_bwd_reduce_grid(p.npix, p.c);
