@@ -77,12 +77,46 @@ __device__ __forceinline__ int swz(int row) { return ((row >> 2) & 1) << 1; }
 // Epilogue of one 16 x 16 base-pixel tile: the wave's four accumulator rows (base rows 4 * wave + mf, column lr) get
 // bias / addend, go to one of the two destinations, and feed the running norm statistics.  Output pixel of base
 // pixel (y, x): base_pix + rel0 + mf * rel_step (the caller folds in image, tile origin, output stride and phase).
-template <class TR, int NFRAG>
+// ADDM: 0 = the addend is a run-time option, loaded row by row; 1 = the caller knows there is none; 2 = there is one
+// and all four rows' addend vectors are requested before the first store (the addend may be the destination itself, a
+// gradient accumulated in place, so left alone the compiler keeps every addend load behind the previous row's store).
+template <class TR, int NFRAG, int ADDM = 0>
 __device__ __forceinline__ void tile_epilogue(const IgemmParams& p, const v4f (&acc)[4][NFRAG], int base_pix, int rel0, int rel_step,
                                               int by0, int bx0, int wave, int lr, int g, int n0, bool do_stats,
                                               float (&s1)[NFRAG][4], float (&s2)[NFRAG][4]) {
     constexpr int ESZ = TR::ESZ;
     const bool full = by0 + 16 <= p.bd[1] && bx0 + 16 <= p.bd[2];
+    constexpr int NV = NFRAG == 1 ? 1 : NFRAG / 2, CW = NFRAG == 1 ? 4 : 8, AW = CW * ESZ / 4;
+    unsigned av[4][NV][AW];                             // ADDM == 2: packed addend vectors of the four rows
+    if (ADDM == 2) {
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) {
+            const bool valid = full || (by0 + wave * 4 + mf < p.bd[1] && bx0 + lr < p.bd[2]);
+            const size_t op = (size_t)(base_pix + (valid ? rel0 + mf * rel_step : 0));     // outside the tensor: the tile's origin, unused
+#pragma unroll
+            for (int pf = 0; pf < NV; ++pf) {
+                const int ch = NFRAG == 1 ? n0 + 4 * g : n0 + 32 * pf + 8 * g;
+                const char* src = p.addend + (op * p.add_pitch + p.add_coff + ch) * ESZ;
+                if constexpr (AW == 2) {
+                    const uint2 t = *reinterpret_cast<const uint2*>(src);
+                    av[mf][pf][0] = t.x; av[mf][pf][1] = t.y;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < AW / 4; ++q) {
+                        const uint4 t = *reinterpret_cast<const uint4*>(src + 16 * q);
+                        av[mf][pf][4 * q] = t.x; av[mf][pf][4 * q + 1] = t.y; av[mf][pf][4 * q + 2] = t.z; av[mf][pf][4 * q + 3] = t.w;
+                    }
+                }
+            }
+        }
+    }
+    auto add_kept = [&](float* v, int mf, int pf) {
+#pragma unroll
+        for (int j = 0; j < CW; ++j) {
+            if constexpr (ESZ == 2) v[j] += __uint_as_float((j & 1) ? (av[mf][pf][j >> 1] & 0xffff0000u) : (av[mf][pf][j >> 1] << 16));
+            else v[j] += __uint_as_float(av[mf][pf][j]);
+        }
+    };
 #pragma unroll
     for (int mf = 0; mf < 4; ++mf) {
         const bool valid = full || (by0 + wave * 4 + mf < p.bd[1] && bx0 + lr < p.bd[2]);
@@ -106,7 +140,8 @@ __device__ __forceinline__ void tile_epilogue(const IgemmParams& p, const v4f (&
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] += p.bias[ch - p.bias_c0 + j];
                 }
-                if (p.addend) {
+                if (ADDM == 2) add_kept(v, mf, 0);
+                if (ADDM == 0 && p.addend) {
                     float a[4];
                     load_n<TR, 4>(p.addend + (op * p.add_pitch + p.add_coff + ch) * ESZ, a);
 #pragma unroll
@@ -126,7 +161,8 @@ __device__ __forceinline__ void tile_epilogue(const IgemmParams& p, const v4f (&
 #pragma unroll
                         for (int j = 0; j < 8; ++j) v[j] += p.bias[ch - p.bias_c0 + j];
                     }
-                    if (p.addend) {
+                    if (ADDM == 2) add_kept(v, mf, pf);
+                    if (ADDM == 0 && p.addend) {
                         float a[8];
                         load_n<TR, 8>(p.addend + (op * p.add_pitch + p.add_coff + ch) * ESZ, a);
 #pragma unroll
@@ -406,7 +442,7 @@ __host__ __device__ constexpr int ph_of_tap(int t) { return t < 1 ? 0 : t < 3 ? 
 __host__ __device__ constexpr int ph_dy(int t) { return (t == 3 || t == 5 || t == 6) ? 1 : 0; }
 __host__ __device__ constexpr int ph_dx(int t) { return (t == 1 || t == 5 || t == 7) ? 1 : 0; }
 
-template <class TR, int NFRAG>
+template <class TR, int NFRAG, bool ADD>     // ADD: the layer has an addend (a kernel of its own: the other keeps the shorter epilogue)
 __global__ __launch_bounds__(256, 2) void conv2d_phase_kernel(const IgemmParams p) {
     constexpr int ESZ = TR::ESZ;
     constexpr int KCE = 64 / ESZ;
@@ -554,7 +590,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_phase_kernel(const IgemmParams 
 #pragma unroll
             for (int ph = 0; ph < 4; ++ph) {
                 const int base_pix = (c_img * p.od[1] + by0 * 2 + (ph >> 1)) * p.od[2] + bx0 * 2 + (ph & 1);
-                tile_epilogue<TR, NFRAG>(p, acc[ph], base_pix, rel0, rel_step, by0, bx0, wave, lr, g, n0, do_stats, s1, s2);
+                tile_epilogue<TR, NFRAG, ADD ? 2 : 1>(p, acc[ph], base_pix, rel0, rel_step, by0, bx0, wave, lr, g, n0, do_stats, s1, s2);
             }
             if (++c_tx == ntx) { c_tx = 0; if (++c_ty == nty) { c_ty = 0; ++c_img; } }
         }
@@ -581,7 +617,7 @@ int launch_conv2d_phase_t(const IgemmParams& pin, hipStream_t st) {
     constexpr int NT = NFRAG * 16;
     const size_t lds = (size_t)2 * 19 * 1024 + (size_t)2 * 9 * NT * 64;
     p.tpw = tiles_per_wg(p, NT);
-    auto kern = conv2d_phase_kernel<TR, NFRAG>;
+    auto kern = p.addend ? conv2d_phase_kernel<TR, NFRAG, true> : conv2d_phase_kernel<TR, NFRAG, false>;
     if (lds > 48 * 1024) {
         hipError_t e = mi_func_set_lds(reinterpret_cast<const void*>(kern), (int)lds);
         if (e != hipSuccess) { mi_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return -2; }
