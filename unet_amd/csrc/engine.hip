@@ -41,6 +41,7 @@ enum StepKind {
     K_KFINISH_NORM      // finishing pass of a split convolution (ig) and the norm forward behind it (nm, relocated by rel_nm) in one launch
 };
 enum Base { B_ARENA, B_PARAMS, B_GRADS, B_XIN, B_LOGITS, B_DLOGITS, B_NBASE };
+constexpr int MI_NFLAG = 64;     // start flags per backward pass (forks released by a kernel's start instead of an event)
 
 struct Reloc { size_t field_off; int base; };
 
@@ -124,6 +125,7 @@ struct mi_unet {
     std::vector<PackDesc> packs; std::vector<int> pack_is_bwd;
     std::vector<ReduceDesc> reduces; std::vector<int> reduce_has_b;
     size_t off_stats = 0, stats_bytes = 0, off_bstats = 0, bstats_bytes = 0;
+    size_t off_flags = 0;                 // MI_NFLAG start flags, 64 bytes apart, inside the backward statistics block (cleared with it)
     double flops_fwd = 0, flops_bwd = 0;
     int n_fwd_packs = 0;
     std::vector<mi_norm_info> norms;      // norm blocks of the forward pass in execution order
@@ -134,6 +136,9 @@ struct mi_unet {
     hipEvent_t join_ev = nullptr;
     hipEvent_t pack_ev = nullptr;         // forward: the first packing launch (weights of the first levels) is done
     int use_side = -1;                    // -1: undecided, 0: off, 1: on
+    int can_wait_value = -1;              // hipStreamWaitValue32 usable on this device (-1: not asked yet)
+    unsigned flag_seq = 0;                // value the start flags of the current backward call take (never 0, changes every call)
+    const void* flag_arena = nullptr;     // workspace whose flag words have been cleared for this plan
     // profiling
     bool prof = false;
     std::vector<ProfEvent> events;
@@ -515,8 +520,11 @@ bool build(mi_unet& u) {
     {
         size_t tot = 0;
         for (int l = 0; l < L; ++l) tot += (size_t)(3 * R + 4) * nb * MI_NSLOT * (size_t)c[l] * 2 * sizeof(double) + 4096;
+        tot += (size_t)MI_NFLAG * 64 + 64;
         u.off_stats = B.alloc(tot); u.stats_bytes = tot;
         u.off_bstats = B.alloc(tot); u.bstats_bytes = tot;
+        B.bstats_cursor = align_up(B.bstats_cursor, 64);
+        u.off_flags = B.bstats_alloc((size_t)MI_NFLAG * 64);
     }
     std::vector<int> Pcat(L);
     // the skip concatenation [encoder output | decoder output] of level l is kept as two contiguous tensors
@@ -1079,7 +1087,7 @@ int run_reduce(mi_unet& u, const Step& s, char* const* bases, hipStream_t st) {
     return 0;
 }
 
-int run_step(mi_unet& u, Step& s, char* const* bases, int training, uint64_t seed, hipStream_t st) {
+int run_step(mi_unet& u, Step& s, char* const* bases, int training, uint64_t seed, hipStream_t st, unsigned* start_flag = nullptr, unsigned start_val = 0) {
     if (!bases_ok(s, bases)) { mi_set_error("step '" + s.layer + "' needs a buffer the caller did not pass"); return -1; }
     switch (s.kind) {
         case K_IGEMM: return launch_igemm(s.dtype, resolve(s, s.ig, bases), st);
@@ -1088,6 +1096,7 @@ int run_step(mi_unet& u, Step& s, char* const* bases, int training, uint64_t see
             NormParams p = resolve_with(s.rel_nm, s.nm, bases);
             p.seed = seed;
             norm_set_dropout(p, training ? u.cfg.dropout : 0.f);
+            if (p.dy) { p.start_flag = start_flag; p.start_val = start_val; }
             return p.dy ? launch_finish_norm_bwd(s.dtype, resolve(s, s.ig, bases), p, st)
                         : launch_finish_norm(s.dtype, resolve(s, s.ig, bases), p, st);
         }
@@ -1097,6 +1106,7 @@ int run_step(mi_unet& u, Step& s, char* const* bases, int training, uint64_t see
             NormParams p = resolve(s, s.nm, bases);
             p.seed = seed;
             norm_set_dropout(p, training ? u.cfg.dropout : 0.f);
+            if (s.kind == K_NORM_BWD) { p.start_flag = start_flag; p.start_val = start_val; }
             return s.kind == K_NORM_FWD ? launch_norm_fwd(s.dtype, p, st) : launch_norm_bwd(s.dtype, p, st);
         }
         case K_C1_FWD: return launch_c1_s2_fwd(s.dtype, resolve(s, s.c1, bases), st);
@@ -1169,7 +1179,43 @@ int run_list(mi_unet& u, std::vector<Step>& list, int backward, int bucket, char
         static const int env = getenv("MI_FORK_BATCH") ? atoi(getenv("MI_FORK_BATCH")) : 0;
         fork_batch = env > 0 ? env : ((long long)u.nb * u.rp[1] < (1ll << 20) ? 4 : 1);
     }
-    Step* deferred[16]; int ndeferred = 0;
+    Step* deferred[16]; int ndeferred = 0; bool deferred_reduce = false;
+    // Forks without a packet on the main stream.  Side-stream steps of the backward pass are collected; when the next
+    // main-stream step is one whose first kernel can raise a start flag (the norm backward kernels), that step is
+    // enqueued first, then the side stream gets a hipStreamWaitValue32 on the flag and the collected steps.  "That
+    // kernel has started" implies everything enqueued before it has completed, which is what an event recorded in
+    // front of it would have said, but a record holds the next kernel back by 2.5-5 us and releases the side stream
+    // ~8 us after the producer ends instead of ~1 us (measured, scripts/micro/wait_value.hip).  The wait is always
+    // enqueued AFTER the kernel that satisfies it, so two streams that share a hardware queue cannot deadlock.
+    // A flag is raised to a value that changes with every call (compare: equal), so neither the previous pass's flags
+    // nor the zeros the first step of every backward pass writes over the block (the flags live in the backward
+    // statistics block) can release a wait early; a workspace this plan has not used before gets its flag words
+    // cleared once, ordered in front of both streams.  In front of any other kind of step, and at the end of the
+    // call, the collected steps are released by an event as before.  Bucket-by-bucket calls (data-parallel training)
+    // use events only: two ranks time-sharing one GPU hung with the flag waits in place (cause not found; every rank of
+    // a real job has a GPU of its own, but the event path is the proven one there).  MI_NO_FLAG_FORK=1: events only.
+    unsigned* flag_base = nullptr;
+    int nflag = 0;
+    if (side && backward && bucket < 0 && bases[B_ARENA]) {
+        static const bool off = getenv("MI_NO_FLAG_FORK") != nullptr;
+        if (u.can_wait_value < 0) {
+            int dev = 0, can = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, dev) != hipSuccess) { (void)hipGetLastError(); can = 0; }
+            u.can_wait_value = can ? 1 : 0;
+        }
+        if (!off && u.can_wait_value == 1) {
+            flag_base = reinterpret_cast<unsigned*>(bases[B_ARENA] + u.off_flags);
+            if (u.flag_seq == 0) u.flag_seq = 0x9e3779b9u * (unsigned)(reinterpret_cast<uintptr_t>(&u) >> 4) | 1u;
+            u.flag_seq += 0x61c88647u;
+            if (u.flag_seq == 0) u.flag_seq = 1;
+            if (u.flag_arena != bases[B_ARENA]) {
+                MI_HIP(hipMemsetAsync(flag_base, 0, (size_t)MI_NFLAG * 64, u.side));
+                MI_HIP(hipEventRecord(u.join_ev, u.side));
+                MI_HIP(hipStreamWaitEvent(st, u.join_ev, 0));
+                u.flag_arena = bases[B_ARENA];
+            }
+        }
+    }
     auto fork = [&]() -> int {      // the side stream waits for everything enqueued on the main stream so far
         if (nside >= u.side_ev.size()) {
             hipEvent_t e;
@@ -1187,35 +1233,36 @@ int run_list(mi_unet& u, std::vector<Step>& list, int backward, int bucket, char
         pending = false;
         return 0;
     };
-    auto flush_deferred = [&]() -> int {     // one fork for all the weight gradients collected so far
-        if (!ndeferred) return 0;
-        if (int r = fork()) return r;
+    auto run_deferred = [&]() -> int {       // the collected steps, in order, on the side stream
         for (int k = 0; k < ndeferred; ++k)
             if (int r = run_step(u, *deferred[k], bases, training, seed, u.side)) return r;
-        ndeferred = 0; pending = true;
+        ndeferred = 0; deferred_reduce = false; pending = true;
         return 0;
     };
+    auto flush_by_event = [&]() -> int {     // one event fork for everything collected so far
+        if (!ndeferred) return 0;
+        if (int r = fork()) return r;
+        return run_deferred();
+    };
+    auto body = [&]() -> int {
     for (size_t i = 0; i < list.size(); ++i) {
         Step& s = list[i];
         if (bucket >= 0 && s.bucket != bucket) continue;
-        if (side && backward && fork_batch > 1) {
-            if (is_wgrad_kind(s.kind)) {
-                deferred[ndeferred++] = &s;
-                if (ndeferred >= fork_batch || ndeferred >= 16) { if (int r = flush_deferred()) return r; }
-                continue;
-            }
-            if (s.kind == K_REDUCE) { if (int r = flush_deferred()) return r; }     // the reduction follows its slabs on the side stream
+        if (side && backward && (is_wgrad_kind(s.kind) || s.kind == K_REDUCE)) {
+            if (ndeferred == 16) { if (int r = flush_by_event()) return r; }
+            deferred[ndeferred++] = &s;
+            if (s.kind == K_REDUCE) deferred_reduce = true;
+            continue;
         }
         ProfEvent ev;
         if (u.prof) {
             MI_HIP(hipEventCreate(&ev.a)); MI_HIP(hipEventCreate(&ev.b));
             MI_HIP(hipEventRecord(ev.a, st));
         }
-        const bool on_side = side && (backward ? (is_wgrad_kind(s.kind) || s.kind == K_REDUCE) : s.kind == K_PACK);
-        if (on_side) {
-            if (backward || !pack_first_pending) { if (int r = fork()) return r; }     // the second packing launch follows the first
+        if (side && !backward && s.kind == K_PACK) {
+            if (!pack_first_pending) { if (int r = fork()) return r; }             // the second packing launch follows the first
             if (int r = run_step(u, s, bases, training, seed, u.side)) return r;
-            if (!backward && !pack_first_pending && !pack_first_done) {
+            if (!pack_first_pending && !pack_first_done) {
                 MI_HIP(hipEventRecord(u.pack_ev, u.side));
                 pack_first_pending = true;
             }
@@ -1226,7 +1273,18 @@ int run_list(mi_unet& u, std::vector<Step>& list, int backward, int bucket, char
                 pack_first_pending = false; pack_first_done = true;
             }
             if (!backward && s.join_side && pending) { if (int r = join()) return r; }
-            if (int r = run_step(u, s, bases, training, seed, st)) return r;
+            // side-stream steps collected in front of this one are released now: several weight gradients share a
+            // fork on small workloads (fork_batch), a gradient reduction never waits for more
+            const bool release = ndeferred && (ndeferred >= fork_batch || deferred_reduce);
+            if (release && flag_base && nflag < MI_NFLAG && (s.kind == K_NORM_BWD || s.kind == K_KFINISH_NORM)) {
+                unsigned* sf = flag_base + (nflag++) * 16;
+                if (int r = run_step(u, s, bases, training, seed, st, sf, u.flag_seq)) return r;
+                MI_HIP(hipStreamWaitValue32(u.side, sf, u.flag_seq, hipStreamWaitValueEq, 0xffffffffu));
+                if (int r = run_deferred()) return r;
+            } else {
+                if (release) { if (int r = flush_by_event()) return r; }
+                if (int r = run_step(u, s, bases, training, seed, st)) return r;
+            }
         }
         if (u.prof) {
             MI_HIP(hipEventRecord(ev.b, st));
@@ -1234,7 +1292,9 @@ int run_list(mi_unet& u, std::vector<Step>& list, int backward, int bucket, char
             u.events.push_back(ev);
         }
     }
-    if (int r = flush_deferred()) return r;
+    return flush_by_event();
+    };
+    if (int r = body()) return r;
     if (pending) { if (int r = join()) return r; }
     return 0;
 }

@@ -100,6 +100,8 @@ struct NormParams {
     int nb, npix, c;
     float eps;
     unsigned long long seed; unsigned layer, drop_thresh; float drop_scale;  // drop_thresh: P(drop) * 65536, 0 = no dropout
+    unsigned* start_flag; unsigned start_val;   // backward: not null -> the first workgroup stores start_val there as the kernel starts (every
+                                            // earlier kernel of the stream is complete then): releases a side stream that waits on it
 };
 // dropout probability -> 16-bit threshold and survivor scale of NormParams
 inline void norm_set_dropout(NormParams& p, float dropout) {

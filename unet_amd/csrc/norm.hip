@@ -11,6 +11,14 @@
 
 namespace {
 
+// "This kernel has started": one relaxed system-scope store by the first workgroup.  A side stream waiting on the word
+// (hipStreamWaitValue32) is released without any packet on this kernel's own stream; what it then reads was written by
+// kernels that completed, caches released, before this one could start.
+__device__ __forceinline__ void signal_start(unsigned* flag, unsigned val) {
+    if (flag && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        __hip_atomic_store(flag, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // mean / rstd of every channel of image `img` into LDS (2 floats per channel); the sums are fp64
 __device__ __forceinline__ void load_moments(const double* stats, int img, int c, int npix, float eps, float* sm) {
     for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
@@ -201,6 +209,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void n
     extern __shared__ __attribute__((aligned(16))) float sm[];  // [c][2] moments, then [256][2*VEC] partials
     __shared__ float red_da[4];
     const int img = blockIdx.y;
+    signal_start(p.start_flag, p.start_val);
     float* part = sm + 2 * p.c;
     load_moments(p.stats, img, p.c, p.npix, p.eps, sm);
     __syncthreads();
@@ -418,6 +427,7 @@ __global__ __launch_bounds__(T) void norm_bwd_small_kernel(const NormParams p, c
     const int img = blockIdx.y;
     const int c0 = blockIdx.x * SM_CG;
     const int npix = p.npix;
+    signal_start(p.start_flag, p.start_val);
     if (threadIdx.x < SM_CG) {
         const int ch = c0 + threadIdx.x;
         double s1 = 0.0, s2 = 0.0;
@@ -714,6 +724,7 @@ template <bool DROP, int W>
 __global__ __launch_bounds__(256) void norm1_bwd_reduce_kernel(const NormParams p) {
     __shared__ float red[3][4];
     const int img = blockIdx.y;
+    signal_start(p.start_flag, p.start_val);
     float mean, rstd;
     c1_moments(p.stats, img, p.npix, p.eps, mean, rstd);
     const float alpha = *p.alpha;
