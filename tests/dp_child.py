@@ -1,4 +1,4 @@
-"""One rank of the two-rank data-parallel rehearsal (started by tests/test_dp_two_rank_gpu.py, never collected itself):
+"""One rank of the two-rank data-parallel rehearsal (started by tests/test_zy_dp_two_rank_gpu.py, never collected itself):
 
     python dp_child.py RANK WORLD PORT OUT.pt
 

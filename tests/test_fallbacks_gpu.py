@@ -18,7 +18,7 @@ from helpers import rel_l2
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 SWITCHES = ["MI_NO_IGEMM_DMA", "MI_NO_CONV_DMA", "MI_NO_CONV_PHASE", "MI_NO_CONV_S2", "MI_NO_CONV_S2_STREAM", "MI_NO_CONV_K16", "MI_NO_WGRAD_DMA", "MI_NO_WGRAD_THICK",
-            "MI_NO_WGRAD_THICK_S2", "MI_NO_WGRAD_THIN", "MI_NO_C1_STRIP", "MI_NO_SIDE_STREAM", "MI_NO_NORM_ON_LOAD", "MI_NO_FINISH_NORM"]
+            "MI_NO_WGRAD_THICK_S2", "MI_NO_WGRAD_THIN", "MI_NO_C1_STRIP", "MI_NO_SIDE_STREAM", "MI_NO_NORM_ON_LOAD", "MI_NO_FINISH_NORM", "MI_NO_FLAG_FORK"]
 
 
 def run_child(tmp_path, switch):
@@ -51,7 +51,7 @@ def test_older_kernels_agree_with_the_default_selection(tmp_path, baseline, swit
         assert ok, (k, rel_l2(d, g), float((d - g).abs().max()), scale)
 
 
-KERNEL_SWITCHES = [s for s in SWITCHES if s not in ("MI_NO_SIDE_STREAM", "MI_NO_NORM_ON_LOAD", "MI_NO_FINISH_NORM")]
+KERNEL_SWITCHES = [s for s in SWITCHES if s not in ("MI_NO_SIDE_STREAM", "MI_NO_NORM_ON_LOAD", "MI_NO_FINISH_NORM", "MI_NO_FLAG_FORK")]
 
 
 def test_older_kernels_meet_the_operator_bounds_against_the_oracle(dev):

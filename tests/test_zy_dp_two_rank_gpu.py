@@ -42,7 +42,8 @@ def _spawn(world, tmp_path, tag):
             low = logs[r].lower()
             if "gloo" in low and ("not supported" in low or "no backend" in low):
                 pytest.skip(f"device tensors not supported by this gloo build:\n{logs[r][-800:]}")
-            raise AssertionError(f"rank {r} failed ({p.returncode}):\n{logs[r][-3000:]}")
+            others = "\n".join(f"--- rank {q} ({procs[q].returncode}) ---\n{logs[q][-2000:]}" for q in range(world) if q != r)
+            raise AssertionError(f"rank {r} failed ({p.returncode}):\n{logs[r][-3000:]}\n{others}")
     return [torch.load(o, weights_only=True) for o in outs]
 
 

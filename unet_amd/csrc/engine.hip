@@ -1198,7 +1198,13 @@ int run_list(mi_unet& u, std::vector<Step>& list, int backward, int bucket, char
     // a real job has a GPU of its own, but the event path is the proven one there).  MI_NO_FLAG_FORK=1: events only.
     unsigned* flag_base = nullptr;
     int nflag = 0;
-    if (side && backward && bucket < 0 && bases[B_ARENA]) {
+    // Small workloads only (the criterion of the fork batching below): on a large batch the weight gradient that
+    // starts ~8 us earlier shares more of the norm backward's HBM time than it gains (same box, flags / events:
+    // headline 2.376 / 2.373 ms, 32-512 widths 5.39 / 5.31 ms; 8 x 256^2 0.80 / 0.87 ms, 96^3 patches 1.63 / 1.68 ms;
+    // raised by the apply pass instead of the reduce pass: 2.44 ms).  MI_FLAG_FORK=1 / 0 forces the choice.
+    static const int flag_env = getenv("MI_FLAG_FORK") ? atoi(getenv("MI_FLAG_FORK")) : -1;
+    const bool flag_wanted = flag_env >= 0 ? flag_env != 0 : (long long)u.nb * u.rp[1] < (1ll << 20);
+    if (side && backward && bucket < 0 && flag_wanted && bases[B_ARENA]) {
         static const bool off = getenv("MI_NO_FLAG_FORK") != nullptr;
         if (u.can_wait_value < 0) {
             int dev = 0, can = 0;
