@@ -167,3 +167,35 @@ def test_optimizer_state_loaded_on_the_cpu_follows_the_model_to_the_gpu(dev):
     torch.cuda.synchronize()
     assert o2._m.is_cuda and o2._step == 4
     assert torch.equal(m1.flat_parameters(), m2.flat_parameters())
+
+
+def test_a_training_step_replays_from_a_captured_graph(dev):
+    """A caller may capture the whole step (forward, loss, backward, AdamW: one library call) into a HIP graph.  The
+    engine's side stream joins the capture through its fork / join events; the start-flag forks of small workloads
+    (stream value waits, which a capture does not take) give way to events while the stream is capturing.  One
+    replay of a captured second step must leave the parameters where an eager second step leaves them."""
+    x = torch.rand(4, 1, 64, 64, device=dev)
+    t = (torch.rand(4, 1, 64, 64, device=dev) > 0.6).float()
+
+    def make():
+        torch.manual_seed(11)
+        m = unet_amd.UNet(2, 1, 1, (16, 32, 64), (2, 2), num_res_units=2, dropout=0.0, compute_dtype=torch.float32).to(dev).train()
+        opt = unet_amd.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-5, model=m)
+        return m, unet_amd.Trainer(m, unet_amd.DiceCELoss(sigmoid=True), opt)
+
+    m_e, tr_e = make()
+    tr_e.step(x, t); tr_e.step(x, t)
+    torch.cuda.synchronize()
+    want = m_e.flat_parameters().detach().clone()
+
+    m_g, tr_g = make()
+    tr_g.step(x, t)                      # eager first step: buffers, plan and side stream exist before the capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        tr_g.step(x, t)
+    graph.replay()
+    torch.cuda.synchronize()
+    got = m_g.flat_parameters().detach()
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, want)

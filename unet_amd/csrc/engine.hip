@@ -1211,7 +1211,13 @@ int run_list(mi_unet& u, std::vector<Step>& list, int backward, int bucket, char
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, dev) != hipSuccess) { (void)hipGetLastError(); can = 0; }
             u.can_wait_value = can ? 1 : 0;
         }
-        if (!off && u.can_wait_value == 1) {
+        bool capturing = false;       // a stream under graph capture takes no value waits: events there
+        {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); capturing = true; }
+            else capturing = cs != hipStreamCaptureStatusNone;
+        }
+        if (!off && !capturing && u.can_wait_value == 1) {
             flag_base = reinterpret_cast<unsigned*>(bases[B_ARENA] + u.off_flags);
             if (u.flag_seq == 0) u.flag_seq = 0x9e3779b9u * (unsigned)(reinterpret_cast<uintptr_t>(&u) >> 4) | 1u;
             u.flag_seq += 0x61c88647u;
