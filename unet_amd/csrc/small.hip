@@ -722,6 +722,54 @@ __global__ __launch_bounds__(256) void stencil_kernel(const StencilParams p) {
     *reinterpret_cast<float4*>(p.out + o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
 }
 
+// 3-D variant through LDS: a workgroup owns S3_TZ x S3_TY x S3_TX outputs (four consecutive x per thread) and stages
+// their input block with a one-pixel halo (in x: one aligned 16-byte group on either side) once; the 27 taps then read
+// LDS.  The per-thread form above fetches every input row nine times through L2 (three planes of a 96^2 image exceed
+// L1): 27 x the tensor; here a block is fetched ~2.3 x.
+constexpr int S3_TZ = 4, S3_TY = 8, S3_TX = 32;
+__global__ __launch_bounds__(256) void stencil3d_tile_kernel(const StencilParams p) {
+    constexpr int PZ = S3_TZ + 2, PY = S3_TY + 2, PQ = S3_TX / 4 + 2;      // planes, rows, 16-byte groups per row
+    __shared__ __attribute__((aligned(16))) float tile[PZ][PY][PQ * 4];
+    const int ntx = (p.d[2] + S3_TX - 1) / S3_TX;
+    const int x0 = (blockIdx.x % ntx) * S3_TX, y0 = (blockIdx.x / ntx) * S3_TY, z0 = blockIdx.y * S3_TZ;
+    const int img = blockIdx.z;
+    const size_t npix = (size_t)p.d[0] * p.d[1] * p.d[2];
+    const float* in = p.in + (size_t)img * npix;
+    for (int i = threadIdx.x; i < PZ * PY * PQ; i += 256) {
+        const int q = i % PQ, py = (i / PQ) % PY, pz = i / (PQ * PY);
+        const int z = z0 - 1 + pz, y = y0 - 1 + py, x = x0 - 4 + 4 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)z < (unsigned)p.d[0] && (unsigned)y < (unsigned)p.d[1] && (unsigned)x < (unsigned)p.d[2])
+            v = *reinterpret_cast<const float4*>(in + ((size_t)z * p.d[1] + y) * p.d[2] + x);
+        *reinterpret_cast<float4*>(&tile[pz][py][4 * q]) = v;
+    }
+    float w[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) w[k] = p.w[p.flip ? 26 - k : k];
+    const float b = p.bias ? p.bias[0] : 0.f;
+    const int tq = threadIdx.x & 7, ty = (threadIdx.x >> 3) & 7, tz = threadIdx.x >> 6;
+    const int z = z0 + tz, y = y0 + ty, x = x0 + 4 * tq;
+    const bool inside = z < p.d[0] && y < p.d[1] && x < p.d[2];
+    const size_t o = (size_t)img * npix + (inside ? ((size_t)z * p.d[1] + y) * p.d[2] + x : 0);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.addend) a = *reinterpret_cast<const float4*>(p.addend + o);     // requested with the block, used at the end
+    __syncthreads();
+    float acc[4] = {b, b, b, b};
+#pragma unroll
+    for (int kz = 0; kz < 3; ++kz)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const float* row = &tile[tz + kz][ty + ky][4 * tq + 4];
+            const float4 c = *reinterpret_cast<const float4*>(row);
+            const float v[6] = {row[-1], c.x, c.y, c.z, c.w, row[4]};
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] += w[(kz * 3 + ky) * 3 + kx] * v[j + kx];
+        }
+    if (inside) *reinterpret_cast<float4*>(p.out + o) = make_float4(acc[0] + a.x, acc[1] + a.y, acc[2] + a.z, acc[3] + a.w);
+}
+
 // 2-D variant: a thread owns four consecutive pixels of ST_R consecutive rows.  All ST_R + 2 input rows are
 // requested before the first use (one 16-byte load plus the two neighbours per row), so each input row is
 // fetched (ST_R + 2) / ST_R times instead of three times and a thread has its whole working set in flight.
@@ -1027,7 +1075,11 @@ int launch_stencil(const StencilParams& p, hipStream_t st) {
     MI_CHECK(!p.nrm_stats || stencil_norm_on_load_ok(p), "this stencil cannot normalise its input on load");
     if (p.d[2] % 4 == 0) {
         const unsigned gx = (unsigned)((npix / 4 + 255) / 256);
-        if (p.ndim == 3) hipLaunchKernelGGL(stencil_kernel<3>, dim3(gx, p.nb), dim3(256), 0, st, p);
+        static const bool tiled = getenv("MI_NO_STENCIL3D_TILE") == nullptr;
+        const long long tiles_xy = (long long)((p.d[2] + S3_TX - 1) / S3_TX) * ((p.d[1] + S3_TY - 1) / S3_TY);
+        if (p.ndim == 3 && tiled && tiles_xy < (1ll << 31) && (p.d[0] + S3_TZ - 1) / S3_TZ <= 65535 && p.nb <= 65535)
+            hipLaunchKernelGGL(stencil3d_tile_kernel, dim3((unsigned)tiles_xy, (p.d[0] + S3_TZ - 1) / S3_TZ, p.nb), dim3(256), 0, st, p);
+        else if (p.ndim == 3) hipLaunchKernelGGL(stencil_kernel<3>, dim3(gx, p.nb), dim3(256), 0, st, p);
         else if (p.d[1] >= 4 * ST_R) {
             const int threads = (p.d[2] >> 2) * ((p.d[1] + ST_R - 1) / ST_R);
             if (p.nrm_stats) hipLaunchKernelGGL(stencil2d_strip_kernel<true>, dim3((threads + 255) / 256, p.nb), dim3(256), 0, st, p);
