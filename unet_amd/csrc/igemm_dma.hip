@@ -69,8 +69,10 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmParams p) {
     const int tapg_pad = CPS == 2 ? ((p.tapg + 1) & ~1) : p.tapg;
     const int niw = tapg_pad * NT / RPI;         // DMA wave-instructions per weight stage
     const int wbytes = niw * 1024;
-    char* const smP = smem;                      // two patch buffers
-    char* const smW = smem + 2 * pbytes;         // two weight buffers
+    // a workgroup that takes a single contraction chunk stages one patch only: one patch buffer, more workgroups per CU
+    const int nkc_wg = p.ksplit > 1 ? (((p.K + KCE - 1) / KCE + p.ksplit - 1) / p.ksplit) : (p.K + KCE - 1) / KCE;
+    char* const smP = smem;                      // two patch buffers (one for a single chunk)
+    char* const smW = smem + (nkc_wg > 1 ? 2 : 1) * pbytes;         // two weight buffers
     const int t_begin = p.phase_start[ph], t_end = p.phase_start[ph + 1];
 
     // ---- per-lane DMA constants ------------------------------------------------------------------------------------
@@ -276,7 +278,10 @@ bool dma_shape(int dtype, const IgemmParams& p, DmaShape* out) {
     const int tapg_pad = cps == 2 ? ((p.tapg + 1) & ~1) : p.tapg;
     for (;; nf >>= 1) {
         const int niw = tapg_pad * nf * 16 / rpi;
-        const size_t lds = (size_t)2 * nip * 1024 + (size_t)2 * niw * 1024;      // >= 4 KiB: covers the epilogue's statistics partials
+        const int kce = cps * 16 / esz, nkc = (p.K + kce - 1) / kce;
+        const int nkc_wg = p.ksplit > 1 ? (nkc + p.ksplit - 1) / p.ksplit : nkc;
+        size_t lds = (size_t)(nkc_wg > 1 ? 2 : 1) * nip * 1024 + (size_t)2 * niw * 1024;
+        if (lds < 4096) lds = 4096;                                              // the epilogue's statistics partials
         if (niw <= 4 * DMA_MAXUW && lds <= 160 * 1024) {
             out->cps = cps; out->nfrag = nf; out->nip = nip; out->niw = niw; out->lds = lds;
             break;
