@@ -50,6 +50,9 @@ CASES = [
     (3, (8, 8, 8), 16, 64, 3, 2, False),
     (3, (4, 4, 4), 64, 16, 3, 2, True),
     (3, (4, 4, 4), 32, 64, 1, 1, False),
+    (3, (10, 12, 20), 32, 64, 3, 2, False),   # 3-D stride-2 gather staged by polyphase components: ragged tiles
+    (3, (12, 8, 16), 128, 32, 3, 2, False),   # the same with several contraction chunks
+    (3, (6, 10, 6), 128, 32, 3, 2, True),     # data gradient of a 3-D transposed convolution (the other stride-2 gather)
 ]
 
 

@@ -179,6 +179,33 @@ inline bool igemm_geometry(const ConvShape& s, int dir, IgemmParams& p, int kidx
                        (t.off[i][2] - p.omin[2]);
         kidx[i] = t.kidx[i];
     }
+    p.comp_mode = 0;
+    if (t.nphase == 1 && p.sa == 2 && s.ndim == 3 && s.ksize == 3) {
+        // slots by polyphase component (see IgemmParams::comp_mode); both gathers with stride 2 (the stride-2
+        // convolution and the data gradient of the transposed convolution) read input pixel 2 o + k - 1
+        p.comp_mode = 1;
+        for (int d = 0; d < 3; ++d) p.cpd[d] = (1 << p.tlog[d]) + 1;
+        int n = 0;
+        for (int c = 0; c < 8; ++c) {
+            const int r[3] = {(c >> 2) & 1, (c >> 1) & 1, c & 1};
+            p.comp_start[c] = n;
+            int cnt[3], kk[3][2], oo[3][2];
+            for (int d = 0; d < 3; ++d) {
+                if (r[d] == 0) { cnt[d] = 1; kk[d][0] = 1; oo[d][0] = 0; }
+                else { cnt[d] = 2; kk[d][0] = 0; oo[d][0] = 0; kk[d][1] = 2; oo[d][1] = 1; }
+            }
+            for (int iz = 0; iz < cnt[0]; ++iz)
+                for (int iy = 0; iy < cnt[1]; ++iy)
+                    for (int ix = 0; ix < cnt[2]; ++ix) {
+                        const int k[3] = {kk[0][iz], kk[1][iy], kk[2][ix]};
+                        kidx[n] = (k[0] * 3 + k[1]) * 3 + k[2];
+                        p.tap_off[n] = (k[0] * p.pd[1] + k[1]) * p.pd[2] + k[2];       // omin = -1: patch offset = k
+                        p.ctap_off[n] = (oo[0][iz] * p.cpd[1] + oo[1][iy]) * p.cpd[2] + oo[2][ix];
+                        ++n;
+                    }
+        }
+        p.comp_start[8] = n;
+    } else
     // one-phase gathers: taps in ascending patch order (a data gradient mirrors the kernel, so its taps come out
     // reversed); kernels with compile-time tap offsets rely on it, the weight packing follows kidx
     if (t.nphase == 1)

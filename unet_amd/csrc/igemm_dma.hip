@@ -62,17 +62,21 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmParams p) {
     const int ph = blockIdx.z % p.nphase;
     const int ksp = blockIdx.z / p.nphase;       // contraction split: which share of the chunks this workgroup takes
     const int bz0 = tzi << p.tlog[0], by0 = tyi << p.tlog[1], bx0 = txi << p.tlog[2];
-    const int PP = p.pd[0] * p.pd[1] * p.pd[2];
-    const int pd12 = p.pd[1] * p.pd[2];
+    // stride-2 gathers stage one polyphase component of the gathered tensor per stage (unit stride inside it)
+    const bool comp = p.comp_mode != 0;
+    const int pdz = comp ? p.cpd[0] : p.pd[0], pdy = comp ? p.cpd[1] : p.pd[1], pdx = comp ? p.cpd[2] : p.pd[2];
+    const int PP = pdz * pdy * pdx;
+    const int pd12 = pdy * pdx;
     const int nip = (PP + RPI - 1) / RPI;        // DMA wave-instructions per patch
     const int pbytes = nip * 1024;
-    const int tapg_pad = CPS == 2 ? ((p.tapg + 1) & ~1) : p.tapg;
+    const int tapg = comp ? 8 : p.tapg;          // taps per stage (component mode: the largest component)
+    const int tapg_pad = CPS == 2 ? ((tapg + 1) & ~1) : tapg;
     const int niw = tapg_pad * NT / RPI;         // DMA wave-instructions per weight stage
     const int wbytes = niw * 1024;
     // a workgroup that takes a single contraction chunk stages one patch only: one patch buffer, more workgroups per CU
     const int nkc_wg = p.ksplit > 1 ? (((p.K + KCE - 1) / KCE + p.ksplit - 1) / p.ksplit) : (p.K + KCE - 1) / KCE;
     char* const smP = smem;                      // two patch buffers (one for a single chunk)
-    char* const smW = smem + (nkc_wg > 1 ? 2 : 1) * pbytes;         // two weight buffers
+    char* const smW = smem + ((nkc_wg > 1 || comp) ? 2 : 1) * pbytes;         // two weight buffers
     const int t_begin = p.phase_start[ph], t_end = p.phase_start[ph + 1];
 
     // ---- per-lane DMA constants ------------------------------------------------------------------------------------
@@ -87,7 +91,11 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmParams p) {
         for (int u = 0; u < DMA_MAXUP; ++u) {
             const int pix = (wave + 4 * u) * RPI + lane / CPS;
             const int pz = fast_div(pix, p.mg_pd12); const int r = pix - pz * pd12;
-            const int py = fast_div(r, p.mg_pd2); const int px = r - py * p.pd[2];
+            const int py = fast_div(r, p.mg_pd2); const int px = r - py * pdx;
+            if (comp) {          // component mode: the patch coordinates (10 bits each), the source pixel follows per stage
+                d_gp[u] = pix < PP ? (pz << 20) | (py << 10) | px : -1;
+                continue;
+            }
             const int iz = iz0 + pz, iy = iy0 + py, ix = ix0 + px;
             const bool ok = pix < PP && (unsigned)iz < (unsigned)p.id[0] && (unsigned)iy < (unsigned)p.id[1] && (unsigned)ix < (unsigned)p.id[2];
             d_gp[u] = ok ? ((img * p.id[0] + iz) * p.id[1] + iy) * p.id[2] + ix : -1;
@@ -103,20 +111,33 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmParams p) {
     }
     const char* const zero = reinterpret_cast<const char*>(g_zero_rows) + cb;
 
-    auto issue_patch = [&](int kc, int buf) {
+    auto issue_patch = [&](int kc, int c, int buf) {
         const char* src; int spb, scoff;
         if (kc < p.in0_c) { src = p.in0; spb = p.in0_pitch * ESZ; scoff = p.in0_coff + kc; }
         else { src = p.in1; spb = p.in1_pitch * ESZ; scoff = p.in1_coff + kc - p.in0_c; }
         const char* base = src + scoff * ESZ + cb;
         char* dst = smP + buf * pbytes + wave * 1024;
+        if (comp) {
+            // component c = (rz, ry, rx): patch pixel (pz, py, px) is input pixel 2 (tile origin + p) - r
+            const int oz = 2 * bz0 - ((c >> 2) & 1), oy = 2 * by0 - ((c >> 1) & 1), ox = 2 * bx0 - (c & 1);
+#pragma unroll
+            for (int u = 0; u < DMA_MAXUP; ++u)
+                if (u < nup) {
+                    const int q = d_gp[u];
+                    const int iz = oz + 2 * (q >> 20), iy = oy + 2 * ((q >> 10) & 1023), ix = ox + 2 * (q & 1023);
+                    const bool ok = q >= 0 && (unsigned)iz < (unsigned)p.id[0] && (unsigned)iy < (unsigned)p.id[1] && (unsigned)ix < (unsigned)p.id[2];
+                    const int gp = ((img * p.id[0] + iz) * p.id[1] + iy) * p.id[2] + ix;
+                    dma16g(ok ? base + (size_t)gp * spb : zero, dst + u * 4096);
+                }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < DMA_MAXUP; ++u)
             if (u < nup) dma16g(d_gp[u] >= 0 ? base + (size_t)d_gp[u] * spb : zero, dst + u * 4096);
     };
-    auto issue_weights = [&](int kc, int tg, int buf) {
+    auto issue_weights = [&](int kc, int tg, int ntg, int buf) {     // rows of taps >= ntg (padding of an odd or short group) are zero rows
         const char* wb = p.w + ((size_t)tg * p.N * p.K + kc) * ESZ;
         char* dst = smW + buf * wbytes + wave * 1024;
-        const int ntg = min(p.tapg, t_end - tg);     // rows of the padding tap of an odd group are zero rows
 #pragma unroll
         for (int u = 0; u < DMA_MAXUW; ++u)
             if (u < nuw) dma16g((int)(w_d[u] >> 27) < ntg ? wb + (w_d[u] & 0x7ffffffu) : zero, dst + u * 4096);
@@ -129,7 +150,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmParams p) {
     for (int mf = 0; mf < 4; ++mf) {
         const int pidx = wave * 64 + mf * 16 + lr;
         const int tx = pidx & mx, ty = (pidx >> p.tlog[2]) & my, tz = pidx >> (p.tlog[2] + p.tlog[1]);
-        a_pix[mf] = ((tz * p.sa) * p.pd[1] + ty * p.sa) * p.pd[2] + tx * p.sa;
+        a_pix[mf] = comp ? (tz * pdy + ty) * pdx + tx : ((tz * p.sa) * pdy + ty * p.sa) * pdx + tx * p.sa;
     }
     const int w_lane = CPS == 4 ? lr * 64 + ((g ^ swz_row(lr)) << 4) : lr * 32 + ((g & 1) << 4);
 
@@ -147,25 +168,32 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmParams p) {
     }
 
     // ---- stages: (chunk, tap group); the loads of stage s + 1 are issued at the top of stage s ---------------------
-    if (kc_begin < kc_end) { issue_patch(kc_begin, 0); issue_weights(kc_begin, t_begin, 0); }
+    // tap groups of a chunk: uniform groups of tapg slots, or the eight components (their patches differ too)
+    const int* const tap_tab = comp ? p.ctap_off : p.tap_off;
+    const int ngrp = comp ? 8 : (t_end - t_begin + tapg - 1) / tapg;
+    auto grp_first = [&](int gi) { return comp ? p.comp_start[gi] : t_begin + gi * tapg; };
+    auto grp_count = [&](int gi) { return comp ? p.comp_start[gi + 1] - p.comp_start[gi] : min(tapg, t_end - (t_begin + gi * tapg)); };
+    if (kc_begin < kc_end) { issue_patch(kc_begin, 0, 0); issue_weights(kc_begin, grp_first(0), grp_count(0), 0); }
     int pbuf = 0, wbuf = 0;
     for (int kc = kc_begin; kc < kc_end; kc += KCE) {
-        for (int tg = t_begin; tg < t_end; tg += p.tapg) {
-            const int ntg = min(p.tapg, t_end - tg);
+        for (int gi = 0; gi < ngrp; ++gi) {
+            const int tg = grp_first(gi), ntg = grp_count(gi);
             // this wave's loads of this stage have landed; after the barrier everybody's have, and everybody has left
             // the previous stage, whose buffers the next stage's loads overwrite
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (tg + p.tapg < t_end) issue_weights(kc, tg + p.tapg, wbuf ^ 1);
-            else if (kc + KCE < kc_end) { issue_patch(kc + KCE, pbuf ^ 1); issue_weights(kc + KCE, t_begin, wbuf ^ 1); }
+            if (gi + 1 < ngrp) {
+                if (comp) issue_patch(kc, gi + 1, pbuf ^ 1);
+                issue_weights(kc, grp_first(gi + 1), grp_count(gi + 1), wbuf ^ 1);
+            } else if (kc + KCE < kc_end) { issue_patch(kc + KCE, 0, pbuf ^ 1); issue_weights(kc + KCE, grp_first(0), grp_count(0), wbuf ^ 1); }
             const char* pbase = smP + pbuf * pbytes;
             const char* wbase = smW + wbuf * wbytes + w_lane;
             // the tap offsets of the stage, fetched once; a full group of nine taps takes the unrolled path, where the
             // fragment reads of a step are not tied to the step before it
             int toffs[9];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) toffs[t] = p.tap_off[tg + min(t, ntg - 1)];
+            for (int t = 0; t < 9; ++t) toffs[t] = tap_tab[tg + min(t, ntg - 1)];
             if (CPS == 4) {
                 if (ntg == 9) {
 #pragma unroll
@@ -186,7 +214,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmParams p) {
                     }
                 } else {
                     for (int tl = 0; tl < ntg; ++tl) {
-                        const int toff = p.tap_off[tg + tl];
+                        const int toff = tap_tab[tg + tl];
                         uint4 bfr[4], afr[NFRAG];
 #pragma unroll
                         for (int mf = 0; mf < 4; ++mf) {
@@ -224,8 +252,8 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmParams p) {
                 } else {
                     const int nsteps = (ntg + 1) >> 1;
                     for (int s = 0; s < nsteps; ++s) {
-                        const int o0 = p.tap_off[tg + 2 * s];
-                        const int o1 = p.tap_off[tg + min(2 * s + 1, ntg - 1)];
+                        const int o0 = tap_tab[tg + 2 * s];
+                        const int o1 = tap_tab[tg + min(2 * s + 1, ntg - 1)];
                         const int toff = (g >> 1) ? o1 : o0;
                         const int tl = 2 * s + (g >> 1);
                         uint4 bfr[4], afr[NFRAG];
@@ -243,8 +271,9 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmParams p) {
                 }
             }
             wbuf ^= 1;
+            if (comp) pbuf ^= 1;
         }
-        pbuf ^= 1;
+        if (!comp) pbuf ^= 1;
     }
     // every load has been waited for at the top of the last stage; the epilogue's own barrier precedes its use of smem
     igemm_epilogue<TR, NFRAG>(p, acc, smem, img, slot, n0, ph, ksp, bz0, by0, bx0);
@@ -259,7 +288,10 @@ bool dma_shape(int dtype, const IgemmParams& p, DmaShape* out) {
     static const bool off = getenv("MI_NO_IGEMM_DMA") != nullptr;
     // the stride-2 scatter phases (one to eight taps per phase, the same patch staged by every phase) stay with the
     // register-staged kernel: measured faster there (96^3 network, 64 -> 16 transposed: 28.6 against 35.6 us)
-    if (off || p.sa != 1 || p.nphase != 1) return false;
+    const bool comp = p.comp_mode != 0 && p.sa == 2;     // stride-2 gather staged by polyphase components
+    if (off || (p.sa != 1 && !comp) || p.nphase != 1) return false;
+    static const bool comp_off = getenv("MI_NO_IGEMM_DMA_S2") != nullptr;
+    if (comp && comp_off) return false;
     const int esz = dtype ? 2 : 4;
     const int kce4 = 64 / esz, kce2 = 32 / esz;
     int cps;
@@ -267,20 +299,22 @@ bool dma_shape(int dtype, const IgemmParams& p, DmaShape* out) {
     else if (p.K % kce2 == 0 && (p.in0_c >= p.K || p.in0_c % kce2 == 0)) cps = 2;
     else return false;
     if (p.N % 16 || p.tlog[0] + p.tlog[1] + p.tlog[2] != 8 || p.tapg < 1 || p.tapg > 9) return false;
+    if (comp && (p.cpd[0] > 1023 || p.cpd[1] > 1023 || p.cpd[2] > 1023 || p.comp_start[8] != 27)) return false;
     if (p.out1 && (p.out0_c % 16 || p.out0_c <= 0 || p.out0_c >= p.N)) return false;
     if (p.ksplit > 1 && (!p.kpart || p.N % 4 || p.N / 4 > 256)) return false;
     int gcps, nf;
     igemm_config(dtype, p, &gcps, &nf);          // the channel tile follows the policy of the register-staged kernel
     const int rpi = 64 / cps;
-    const long long PP = (long long)p.pd[0] * p.pd[1] * p.pd[2];
+    const long long PP = comp ? (long long)p.cpd[0] * p.cpd[1] * p.cpd[2] : (long long)p.pd[0] * p.pd[1] * p.pd[2];
     const int nip = (int)((PP + rpi - 1) / rpi);
     if (nip > 4 * DMA_MAXUP) return false;
-    const int tapg_pad = cps == 2 ? ((p.tapg + 1) & ~1) : p.tapg;
+    const int tapg = comp ? 8 : p.tapg;
+    const int tapg_pad = cps == 2 ? ((tapg + 1) & ~1) : tapg;
     for (;; nf >>= 1) {
         const int niw = tapg_pad * nf * 16 / rpi;
         const int kce = cps * 16 / esz, nkc = (p.K + kce - 1) / kce;
         const int nkc_wg = p.ksplit > 1 ? (nkc + p.ksplit - 1) / p.ksplit : nkc;
-        size_t lds = (size_t)(nkc_wg > 1 ? 2 : 1) * nip * 1024 + (size_t)2 * niw * 1024;
+        size_t lds = (size_t)((nkc_wg > 1 || comp) ? 2 : 1) * nip * 1024 + (size_t)2 * niw * 1024;
         if (lds < 4096) lds = 4096;                                              // the epilogue's statistics partials
         if (niw <= 4 * DMA_MAXUW && lds <= 160 * 1024) {
             out->cps = cps; out->nfrag = nf; out->nip = nip; out->niw = niw; out->lds = lds;
@@ -299,7 +333,8 @@ template <class TR, int CPS, int NFRAG>
 int launch_dma_t(const IgemmParams& pin, const DmaShape& sh, hipStream_t st) {
     IgemmParams p = pin;
     if (!p.out1) p.out0_c = p.N;
-    p.mg_pd2 = magic_of_d(p.pd[2]); p.mg_pd12 = magic_of_d(p.pd[1] * p.pd[2]);
+    if (p.comp_mode && p.sa == 2) { p.mg_pd2 = magic_of_d(p.cpd[2]); p.mg_pd12 = magic_of_d(p.cpd[1] * p.cpd[2]); }
+    else { p.mg_pd2 = magic_of_d(p.pd[2]); p.mg_pd12 = magic_of_d(p.pd[1] * p.pd[2]); }
     auto kern = igemm_dma_kernel<TR, CPS, NFRAG>;
     if (sh.lds > 48 * 1024) {
         hipError_t e = mi_func_set_lds(reinterpret_cast<const void*>(kern), (int)sh.lds);

@@ -40,6 +40,15 @@ struct IgemmParams {
     int kpart_blocked;                      // partial sums as [ksplit][image][N / 8][pixel of the image][8] instead: the layout
                                             // launch_finish_norm reads (a workgroup there owns one image and eight channels)
     int tpw;                                // 2-D specialisation: consecutive tiles per workgroup, filled in by the launcher
+    // 3-D gathers with stride 2 (sa = 2, one phase): the tap slots are ordered by polyphase component of the gathered
+    // tensor (component c = (rz, ry, rx): pixels 2 i - r per dimension; a tap with k = 1 lives in r = 0 at offset 0,
+    // k = 0 and k = 2 in r = 1 at offsets 0 and 1), comp_start[c] .. comp_start[c + 1] are the slots of component c,
+    // ctap_off their pixel offsets inside a component patch of cpd pixels (tile + 1 per dimension), in which the
+    // gather has unit stride.  tap_off / pd describe the same slots for a kernel that stages the whole strided patch.
+    int comp_mode;
+    int comp_start[9];
+    int ctap_off[MI_MAX_TAPS];
+    int cpd[3];
 };
 
 // Weight-gradient launch: partial[slab][tap][f][s] = sum_{base pixels of the slab}
