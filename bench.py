@@ -330,6 +330,9 @@ def main():
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the side measurements of the other BASELINE.json workloads (3-D patches, inference, batch 8 x 256^2)")
     ap.add_argument("--no-overlap", action="store_true", help="all-reduce after the whole backward")
+    ap.add_argument("--force-reducer", action="store_true",
+                    help="run the bucketed all-reduce path in a process group of one rank (what a rank of a data-parallel job "
+                         "pays for the bucket-by-bucket backward and the communication stream, without a peer); needs torchrun")
     ap.add_argument("--host-input", action="store_true",
                     help="train mode: every step's batch starts in pinned host memory (fp32 image and label) and is copied "
                          "over PCIe on a copy stream, double-buffered; reports the PCIe-inclusive rate, never the headline value")
@@ -373,7 +376,7 @@ def main():
     broadcast_parameters(model.flat_parameters())
     loss = unet_amd.DiceLoss(sigmoid=True, fold_label_two=True)
     opt = unet_amd.AdamW(model.parameters(), lr=5e-4, weight_decay=1e-5, model=model)
-    trainer = unet_amd.Trainer(model, loss, opt, overlap=not args.no_overlap)
+    trainer = unet_amd.Trainer(model, loss, opt, overlap=not args.no_overlap, force_reducer=args.force_reducer)
     x, t = synthetic_batch(args.batch, sp, 1234 + rank, dev)
 
     def sync_all():

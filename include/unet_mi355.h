@@ -81,6 +81,15 @@ int mi_unet_forward(mi_unet* u, const float* params, const float* x, float* logi
  * bucket i returns, everything that writes bucket i's range of `grads` has been enqueued on `stream`. */
 int mi_unet_backward(mi_unet* u, const float* params, const float* x, const float* dlogits, float* grads,
                      void* workspace, int training, uint64_t seed, int bucket, void* stream);
+/* The same for ONE bucket of a data-parallel step (reference/train.py:117 under a gradient exchange): the weight
+ * gradients and the gradient reduction of the bucket run on the plan's internal stream, and when this call returns it
+ * is `ready_stream` (the stream that will exchange the bucket), not `stream`, that waits for them: `stream` goes on with
+ * the next bucket's chain at once instead of idling until the bucket's last weight gradient has finished (measured:
+ * 2.53 -> 2.38 ms per step of the 32 x 512^2 benchmark in bucket-by-bucket mode, 2.37 ms as one call).  The caller makes `stream` wait for
+ * `ready_stream` before anything on `stream` reads `grads` or reuses the workspace (the optimizer step, the next
+ * forward).  ready_stream == NULL: exactly mi_unet_backward. */
+int mi_unet_backward_bucket(mi_unet* u, const float* params, const float* x, const float* dlogits, float* grads,
+                            void* workspace, int training, uint64_t seed, int bucket, void* stream, void* ready_stream);
 
 /* One optimisation step in one call: the body of the reference's inner loop, reference/train.py:111-118
  * (labels==2 -> 1 folded into the loss read, model(inputs), loss_function(outputs, labels), loss.backward(),

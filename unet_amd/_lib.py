@@ -89,6 +89,7 @@ PROTOTYPES = {
     "mi_unet_num_steps": (C.c_int, [_P, C.c_int]),
     "mi_unet_forward": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_uint64, _P]),
     "mi_unet_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_uint64, C.c_int, _P]),
+    "mi_unet_backward_bucket": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_uint64, C.c_int, _P, _P]),
     "mi_unet_train_step": (C.c_int, [_P, C.POINTER(MiTrainStepArgs), _P]),
     "mi_unet_prof_enable": (C.c_int, [_P, C.c_int]),
     "mi_unet_prof_collect": (C.c_int, [_P]),

@@ -1156,7 +1156,7 @@ unsigned fork_event_flags() {
 }
 
 int run_list(mi_unet& u, std::vector<Step>& list, int backward, int bucket, char* const* bases, int training, uint64_t seed,
-             hipStream_t st) {
+             hipStream_t st, hipStream_t join_to = nullptr) {
     // A second stream runs work that is off the critical chain: in the backward pass the weight gradients and
     // the slab reductions (joined at the end of the call), in the forward pass the weight packing (joined in
     // front of the first kernel that reads packed weights).  Timing runs stay on one stream.
@@ -1253,6 +1253,12 @@ int run_list(mi_unet& u, std::vector<Step>& list, int backward, int bucket, char
         pending = false;
         return 0;
     };
+    auto join_other = [&](hipStream_t other) -> int {      // another stream of the caller waits instead; the main stream goes on
+        MI_HIP(hipEventRecord(u.join_ev, u.side));
+        MI_HIP(hipStreamWaitEvent(other, u.join_ev, 0));
+        pending = false;
+        return 0;
+    };
     auto run_deferred = [&]() -> int {       // the collected steps, in order, on the side stream
         for (int k = 0; k < ndeferred; ++k)
             if (int r = run_step(u, *deferred[k], bases, training, seed, u.side)) return r;
@@ -1322,6 +1328,7 @@ int run_list(mi_unet& u, std::vector<Step>& list, int backward, int bucket, char
     return flush_by_event();
     };
     if (int r = body()) return r;
+    if (join_to && side) return join_other(join_to);       // also when nothing is pending: earlier calls' work may still run
     if (pending) { if (int r = join()) return r; }
     return 0;
 }
@@ -1425,6 +1432,17 @@ int mi_unet_backward(mi_unet* u, const float* params, const float* x, const floa
     bases[B_DLOGITS] = (char*)dlogits; bases[B_XIN] = (char*)x;
     hipStream_t st = (hipStream_t)stream;
     return run_list(*u, u->bwd, 1, bucket, bases, training, seed, st);
+}
+
+int mi_unet_backward_bucket(mi_unet* u, const float* params, const float* x, const float* dlogits, float* grads, void* workspace,
+                            int training, uint64_t seed, int bucket, void* stream, void* ready_stream) {
+    MI_CHECK(u && params && x && dlogits && grads && workspace, "null argument");
+    MI_CHECK(u->cfg.with_backward, "plan was created without a backward pass");
+    MI_CHECK(bucket >= 0 && bucket < MI_NUM_BUCKETS, "bucket must be in [0, MI_NUM_BUCKETS)");
+    char* bases[B_NBASE] = {nullptr};
+    bases[B_ARENA] = (char*)workspace; bases[B_PARAMS] = (char*)params; bases[B_GRADS] = (char*)grads;
+    bases[B_DLOGITS] = (char*)dlogits; bases[B_XIN] = (char*)x;
+    return run_list(*u, u->bwd, 1, bucket, bases, training, seed, (hipStream_t)stream, (hipStream_t)ready_stream);
 }
 
 static int train_step_body(mi_unet* u, const mi_train_step_args* a, void* stream);

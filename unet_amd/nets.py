@@ -187,7 +187,15 @@ class _Plan:
                                             1 if training else 0, C.c_uint64(seed), _lib.current_stream(x.device)),
                    "mi_unet_forward")
 
-    def backward(self, flat, x, dlogits, flat_grad, ws, training, seed, bucket=-1):
+    def backward(self, flat, x, dlogits, flat_grad, ws, training, seed, bucket=-1, ready_stream=None):
+        """``ready_stream`` (a ``torch.cuda.Stream``, with ``bucket >= 0``): that stream, not the current one, waits for
+        the bucket's weight gradients and gradient reduction (``mi_unet_backward_bucket``)."""
+        if ready_stream is not None and bucket >= 0:
+            _lib.check(self.lib.mi_unet_backward_bucket(self.h, flat.data_ptr(), x.data_ptr(), dlogits.data_ptr(), flat_grad.data_ptr(),
+                                                        ws.data_ptr(), 1 if training else 0, C.c_uint64(seed), bucket,
+                                                        _lib.current_stream(dlogits.device), C.c_void_p(ready_stream.cuda_stream)),
+                       "mi_unet_backward_bucket")
+            return
         _lib.check(self.lib.mi_unet_backward(self.h, flat.data_ptr(), x.data_ptr(), dlogits.data_ptr(), flat_grad.data_ptr(),
                                              ws.data_ptr(), 1 if training else 0, C.c_uint64(seed), bucket,
                                              _lib.current_stream(dlogits.device)),

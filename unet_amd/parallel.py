@@ -59,6 +59,11 @@ class BucketedAllReduce:
         self._works: List = []
         self._comm_stream = torch.cuda.Stream(flat.device) if flat.is_cuda else None
 
+    @property
+    def comm_stream(self):
+        """The stream the collectives are issued under (``None`` on CPU tensors)."""
+        return self._comm_stream
+
     def launch(self, i: int) -> None:
         if self.world == 1 and not self.force:
             return
@@ -76,9 +81,9 @@ class BucketedAllReduce:
             self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait(self) -> None:
-        if not self._works:
+        if not self._works and self._comm_stream is None:
             return
-        if self._comm_stream is not None:
+        if self._comm_stream is not None:       # also without collectives: the stream may carry waits the caller handed it
             with torch.cuda.stream(self._comm_stream):
                 for w in self._works:
                     w.wait()              # RCCL: the communication stream waits; host-side backends: the host does

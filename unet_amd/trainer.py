@@ -125,8 +125,11 @@ class Trainer:
                                            b["sums"].data_ptr(), 0, 1.0, b["dlogits"].data_ptr(), st),
                    "mi_dice_ce_loss_bwd")
         if self._reducer is not None and self.overlap:
+            # the communication stream, not the compute stream, waits for a bucket's weight gradients and reduction:
+            # the compute stream goes on with the next bucket's chain; reducer.wait() joins everything before AdamW
+            comm = self._reducer.comm_stream
             for bucket in range(len(self._reducer.buckets)):
-                plan.backward(flat, x, b["dlogits"], self._grad, b["ws"], True, seed, bucket)
+                plan.backward(flat, x, b["dlogits"], self._grad, b["ws"], True, seed, bucket, ready_stream=comm)
                 self._reducer.launch(bucket)
             self._reducer.wait()
         else:
