@@ -360,6 +360,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_thick_s2_kernel(const WgradParam
     // (IY, IX), four MFMAs
 #define WG3_TAP(T, CS, IY, IX)                                                                                          \
     do {                                                                                                                \
+        const uint4* afr = afrk[kk];                                                                                    \
         uint4 bfr_[SF];                                                                                                 \
         _Pragma("unroll") for (int b = 0; b < SF; ++b) {                                                                 \
             const char* base_ = smS + (CS) * CBYTES + (2 * ks + (IY)) * PD * ROWS;                                      \
@@ -377,6 +378,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_thick_s2_kernel(const WgradParam
     for (int j = 0; j < 3; ++j) issue_next();
     for (int hs = 0; hs < nhs; ++hs) {
         const char* sF = smF + (hs & 1) * FBYTES;
+        uint4 afrk[2][2];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             // the loads of the next two sub-stages may stay in flight (the third is issued below)
@@ -393,23 +395,29 @@ __global__ __launch_bounds__(256, 2) void wgrad_thick_s2_kernel(const WgradParam
             __builtin_amdgcn_s_barrier();            // sub-stage 4 hs + k has landed everywhere, the one before has been consumed
             asm volatile("" ::: "memory");
             issue_next();
-#pragma unroll 1
+            if (k == 0) {
+                // the fixed-operand fragments of the wave's two k-steps are read once per half tile (its image stays in
+                // its slot for all four sub-stages) and kept in registers: 8 instead of 32 transposed reads
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        const int ks = 2 * kk + wk;
+                        v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(sF + fa0[0][a] + ks * 32 * ROWF));
+                        v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(sF + fa0[1][a] + ks * 32 * ROWF));
+                        v8s f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        afrk[kk][a] = __builtin_bit_cast(uint4, f);
+                    }
+            }
+#pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const int ks = 2 * kk + wk;          // this wave's k-steps of the half tile
-                uint4 afr[2];
-#pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(sF + fa0[0][a] + ks * 32 * ROWF));
-                    v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(sF + fa0[1][a] + ks * 32 * ROWF));
-                    v8s f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    afr[a] = __builtin_bit_cast(uint4, f);
-                }
                 if (k == 0) {
                     if (do_bias) {
                         const uint4 ones = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
 #pragma unroll
                         for (int a = 0; a < 2; ++a)
-                            accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, afr[a]), __builtin_bit_cast(v8bf, ones), accb[a], 0, 0, 0);
+                            accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, afrk[kk][a]), __builtin_bit_cast(v8bf, ones), accb[a], 0, 0, 0);
                     }
                     WG3_TAP(4, 0, 0, 0);             // component (0,0): tap (1,1)
                 } else if (k == 1) {
