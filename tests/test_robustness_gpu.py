@@ -199,3 +199,30 @@ def test_a_training_step_replays_from_a_captured_graph(dev):
     got = m_g.flat_parameters().detach()
     assert torch.isfinite(got).all()
     assert torch.equal(got, want)
+
+
+def test_bucket_calls_with_a_ready_stream_give_the_whole_pass_bit_for_bit(dev):
+    """``mi_unet_backward_bucket``: the four bucket calls, each handing the wait for its weight gradients to another
+    stream (as the data-parallel trainer hands it to the communication stream), leave exactly the gradients of the
+    one-call backward pass once the two streams have been joined."""
+    torch.manual_seed(4)
+    m = unet_amd.UNet(2, 1, 1, (16, 32, 64, 128), (2, 2, 2), num_res_units=2, dropout=0.1, compute_dtype=torch.bfloat16).to(dev).train()
+    x = torch.rand(4, 1, 64, 64, device=dev)
+    dlog = torch.randn(4, 1, 64, 64, device=dev) * 1e-3
+    plan = m._plan_for(x, True)
+    flat = m._ensure_flat(dev)
+    ws = torch.empty(plan.workspace_bytes, dtype=torch.uint8, device=dev)
+    logits = torch.empty_like(x)
+    plan.forward(flat, x, logits, ws, True, 9)
+    g_all = torch.zeros_like(flat)
+    plan.backward(flat, x, dlog, g_all, ws, True, 9)
+    torch.cuda.synchronize()
+    other = torch.cuda.Stream(dev)
+    g_b = torch.zeros_like(flat)
+    nbuckets = len(plan.bucket_ranges())
+    for b in range(nbuckets):
+        plan.backward(flat, x, dlog, g_b, ws, True, 9, bucket=b, ready_stream=other)
+    torch.cuda.current_stream(dev).wait_stream(other)
+    torch.cuda.synchronize()
+    assert nbuckets == 4
+    assert torch.equal(g_b, g_all) and torch.isfinite(g_b).all()
