@@ -46,6 +46,8 @@ CASES = [
     (2, (36, 28), 16, 32, 3, 2, False),      # the same with stride 2
     (2, (14, 10), 64, 16, 3, 2, True),       # its data gradient gathers 16 channels with stride 2
     (3, (8, 8, 8), 16, 16, 3, 1, False),
+    (3, (6, 10, 20), 16, 16, 3, 1, False),    # 3-D, 16 contraction channels (bf16: tap pairs, fragments shared over kernel rows): ragged in z, y and x
+    (3, (9, 5, 33), 16, 32, 3, 1, False),     # the same with two channel blocks and odd extents
     (3, (4, 8, 12), 32, 64, 3, 1, False),
     (3, (8, 8, 8), 16, 64, 3, 2, False),
     (3, (4, 4, 4), 64, 16, 3, 2, True),
@@ -117,6 +119,13 @@ def test_conv_exact_integer_data(dev, mode):
         assert y_ref.abs().max() < 256  # exactly representable in bf16
         y = ops.conv_forward(to_cl(x, dt, dev), w.to(dev), None, ksize=3, stride=stride, transposed=transposed)
         assert torch.equal(from_cl(y), y_ref)
+    # 3-D with 16 contraction channels (bf16: the kernel that pairs taps inside a contraction step)
+    x = torch.randint(-2, 3, (2, 16, 7, 9, 21), generator=g).float()
+    w = torch.randint(-1, 2, (16, 16, 3, 3, 3), generator=g).float()
+    y_ref = _conv_ref(x, w, None, 1, False, 3)
+    assert y_ref.abs().max() < 256
+    y = ops.conv_forward(to_cl(x, dt, dev), w.to(dev), None, ksize=3, stride=1, transposed=False)
+    assert torch.equal(from_cl(y), y_ref)
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])

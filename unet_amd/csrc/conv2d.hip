@@ -80,18 +80,20 @@ __device__ __forceinline__ int swz(int row) { return ((row >> 2) & 1) << 1; }
 // ADDM: 0 = the addend is a run-time option, loaded row by row; 1 = the caller knows there is none; 2 = there is one
 // and all four rows' addend vectors are requested before the first store (the addend may be the destination itself, a
 // gradient accumulated in place, so left alone the compiler keeps every addend load behind the previous row's store).
-template <class TR, int NFRAG, int ADDM = 0>
+// G3: the tile is a 3-D one (wave = z plane, mf = y row): by0 then carries the validity of the wave's four rows as a
+// bit mask and bx0 that of the lane's column.
+template <class TR, int NFRAG, int ADDM = 0, bool G3 = false>
 __device__ __forceinline__ void tile_epilogue(const IgemmParams& p, const v4f (&acc)[4][NFRAG], int base_pix, int rel0, int rel_step,
                                               int by0, int bx0, int wave, int lr, int g, int n0, bool do_stats,
                                               float (&s1)[NFRAG][4], float (&s2)[NFRAG][4]) {
     constexpr int ESZ = TR::ESZ;
-    const bool full = by0 + 16 <= p.bd[1] && bx0 + 16 <= p.bd[2];
+    const bool full = !G3 && by0 + 16 <= p.bd[1] && bx0 + 16 <= p.bd[2];
     constexpr int NV = NFRAG == 1 ? 1 : NFRAG / 2, CW = NFRAG == 1 ? 4 : 8, AW = CW * ESZ / 4;
     unsigned av[4][NV][AW];                             // ADDM == 2: packed addend vectors of the four rows
     if (ADDM == 2) {
 #pragma unroll
         for (int mf = 0; mf < 4; ++mf) {
-            const bool valid = full || (by0 + wave * 4 + mf < p.bd[1] && bx0 + lr < p.bd[2]);
+            const bool valid = G3 ? (((by0 >> mf) & 1) && bx0) : (full || (by0 + wave * 4 + mf < p.bd[1] && bx0 + lr < p.bd[2]));
             const size_t op = (size_t)(base_pix + (valid ? rel0 + mf * rel_step : 0));     // outside the tensor: the tile's origin, unused
 #pragma unroll
             for (int pf = 0; pf < NV; ++pf) {
@@ -119,7 +121,7 @@ __device__ __forceinline__ void tile_epilogue(const IgemmParams& p, const v4f (&
     };
 #pragma unroll
     for (int mf = 0; mf < 4; ++mf) {
-        const bool valid = full || (by0 + wave * 4 + mf < p.bd[1] && bx0 + lr < p.bd[2]);
+        const bool valid = G3 ? (((by0 >> mf) & 1) && bx0) : (full || (by0 + wave * 4 + mf < p.bd[1] && bx0 + lr < p.bd[2]));
         if (do_stats) {
 #pragma unroll
             for (int nf = 0; nf < NFRAG; ++nf)
@@ -1157,6 +1159,166 @@ int launch_conv2d_s2k16_t(const IgemmParams& pin, hipStream_t st) {
     return 0;
 }
 
+// ---- 3-D, 16 contraction channels (bf16), 3 x 3 x 3 taps, unit stride ------------------------------------------------
+// Tile = 4 (z, one plane per wave) x 4 (y, one row per accumulator) x 16 (x) base pixels on a 6 x 6 x 18 patch of
+// 32-byte pixel rows.  Two taps share an MFMA contraction step as in conv2d_k16_kernel, paired so that a pixel
+// fragment depends on the patch row y' = y + dy only, not on (y, dy).  Per patch row there are five fragments,
+//   kind dz = 0..2: pixels (z + dz, y', x | x + 1)       taps (dz, dy, 0) | (dz, dy, 1)
+//   kind 3        : pixels (z | z + 1, y', x + 2)        taps (0, dy, 2)  | (1, dy, 2)
+//   kind 4        : pixel  (z + 2, y', x + 2)            tap  (2, dy, 2)  | zero weights
+// and every fragment read from LDS feeds up to three accumulator rows (y = y' - dy): 30 fragment reads for 60 MFMAs
+// per wave and tile, where a tap-major loop takes 70 reads for 56.  The 15 weight fragments of a lane stay in
+// registers for the life of the workgroup; patches are double-buffered over the workgroup's tiles.  A generic tile
+// of this size spends ten times the cycles of its MFMAs on per-tile address set-up: here that is six DMA requests
+// per wave and tile with precomputed offsets.
+constexpr int C3_PDY = 6, C3_PDX = 18, C3_PP = 6 * C3_PDY * C3_PDX;      // 648 patch pixels
+constexpr int C3_NIP = (C3_PP + 31) / 32;       // 21 DMA wave-instructions per patch (32 pixels each)
+constexpr int C3_PBYTES = C3_NIP * 1024;
+constexpr int C3_NUP = (C3_NIP + 3) / 4;
+
+__global__ __launch_bounds__(256, 2) void conv3d_k16_kernel(const IgemmParams p) {
+    using TR = BF16;
+    constexpr int ESZ = 2;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, g = lane >> 4, hi = g >> 1, half = g & 1;
+    const int D = p.id[0], H = p.id[1], W = p.id[2];
+    const int ntx = p.ntile[2], nty = p.ntile[1], ntz = p.ntile[0];
+    const int tile0 = blockIdx.x * p.tpw;
+    const int n0 = blockIdx.y * 16;
+    const int slot = blockIdx.x % MI_NSLOT;
+    const int spb = p.in0_pitch * ESZ;
+
+    int d_off[C3_NUP], d_zyx[C3_NUP];
+#pragma unroll
+    for (int u = 0; u < C3_NUP; ++u) {
+        const int pix = ((wave + 4 * u) % C3_NIP) * 32 + (lane >> 1);
+        const int pz = pix / (C3_PDY * C3_PDX), r = pix - pz * (C3_PDY * C3_PDX);
+        const int py = r / C3_PDX, px = r - py * C3_PDX;
+        d_off[u] = ((pz * H + py) * W + px) * spb + (lane & 1) * 16;
+        d_zyx[u] = pix < C3_PP ? ((pz << 20) | (py << 10) | px) : -1;
+    }
+    const char* const zero = reinterpret_cast<const char*>(g_zero_page) + (lane & 1) * 16;
+
+    int q_img, q_tz, q_ty, q_tx, q_tile = 0;
+    {
+        const int tiles_img = ntx * nty * ntz;
+        q_img = tile0 / tiles_img;
+        int r = tile0 - q_img * tiles_img;
+        q_tz = r / (ntx * nty); r -= q_tz * ntx * nty;
+        q_ty = r / ntx; q_tx = r - q_ty * ntx;
+    }
+    int c_img = q_img, c_tz = q_tz, c_ty = q_ty, c_tx = q_tx;
+    const int img_wg = q_img;
+
+    auto issue_next = [&]() {
+        if (q_tile < p.tpw) {
+            const int iz0 = (q_tz << 2) - 1, iy0 = (q_ty << 2) - 1, ix0 = (q_tx << 4) - 1;
+            const bool interior = iz0 >= 0 && iy0 >= 0 && ix0 >= 0 && iz0 + 6 <= D && iy0 + C3_PDY <= H && ix0 + C3_PDX <= W;
+            const char* pb = p.in0 + ((((long long)q_img * D + iz0) * H + iy0) * W + ix0) * spb + p.in0_coff * ESZ;
+            char* dst = smem + (q_tile & 1) * C3_PBYTES;
+#pragma unroll
+            for (int u = 0; u < C3_NUP; ++u) {
+                const int i = (wave + 4 * u) % C3_NIP;
+                bool ok = d_zyx[u] >= 0;
+                if (!interior)
+                    ok = ok && (unsigned)(iz0 + (d_zyx[u] >> 20)) < (unsigned)D && (unsigned)(iy0 + ((d_zyx[u] >> 10) & 1023)) < (unsigned)H &&
+                         (unsigned)(ix0 + (d_zyx[u] & 1023)) < (unsigned)W;
+                dma16(ok ? pb + d_off[u] : zero, dst + i * 1024);
+            }
+        }
+        ++q_tile;
+        if (++q_tx == ntx) { q_tx = 0; if (++q_ty == nty) { q_ty = 0; if (++q_tz == ntz) { q_tz = 0; ++q_img; } } }
+    };
+    issue_next();
+
+    // the lane's weight fragments: row n0 + lr of tap (dz, dy, dx), contraction half `half`
+    uint4 wf[3][5];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int t = k < 3 ? k * 9 + dy * 3 + hi : k == 3 ? hi * 9 + dy * 3 + 2 : (hi ? -1 : 18 + dy * 3 + 2);
+            wf[dy][k] = t >= 0 ? *reinterpret_cast<const uint4*>(p.w + ((size_t)(t * p.N + n0 + lr) * 16 + half * 8) * ESZ) : uint4{0u, 0u, 0u, 0u};
+        }
+    // LDS byte offsets of the five fragment kinds at patch row 0 (a patch row is C3_PDX * 32 bytes further on)
+    int fb[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int pz = k < 3 ? wave + k : k == 3 ? wave + hi : wave + 2;
+        const int px = k < 3 ? lr + hi : lr + 2;
+        fb[k] = ((pz * C3_PDY) * C3_PDX + px) * 32 + half * 16;
+    }
+
+    const bool do_stats = p.stats != nullptr;
+    float s1[1][4], s2[1][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s1[0][j] = 0.f; s2[0][j] = 0.f; }
+    const int plane = p.od[1] * p.od[2];
+    const int rel0 = wave * plane + lr;
+
+    for (int tile = 0; tile < p.tpw; ++tile) {
+        const char* pbuf = smem + (tile & 1) * C3_PBYTES;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue_next();       // into the other buffer: every wave has left the tile that read it
+        v4f acc[4][1];
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) acc[mf][0] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int yp = 0; yp < C3_PDY; ++yp) {
+            uint4 F[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) F[k] = *reinterpret_cast<const uint4*>(pbuf + fb[k] + yp * C3_PDX * 32);
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int mf = yp - dy;
+                if (mf >= 0 && mf < 4) {
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) acc[mf][0] = mma16v<TR>(wf[dy][k], F[k], acc[mf][0]);
+                }
+            }
+        }
+        const int bz0 = c_tz << 2, by0 = c_ty << 2, bx0 = c_tx << 4;
+        const int base_pix = ((c_img * p.od[0] + bz0) * p.od[1] + by0) * p.od[2] + bx0;
+        int rows = 0;
+        if (bz0 + wave < p.bd[0]) {
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf) rows |= (by0 + mf < p.bd[1]) << mf;
+        }
+        if (++c_tx == ntx) { c_tx = 0; if (++c_ty == nty) { c_ty = 0; if (++c_tz == ntz) { c_tz = 0; ++c_img; } } }
+        tile_epilogue<TR, 1, 0, true>(p, acc, base_pix, rel0, p.od[2], rows, bx0 + lr < p.bd[2], wave, lr, g, n0, do_stats, s1, s2);
+    }
+    if (do_stats) flush_stats<1>(p, smem, s1, s2, wave, lr, g, n0, img_wg, slot);
+}
+
+int launch_conv3d_k16_t(const IgemmParams& pin, hipStream_t st) {
+    IgemmParams p = pin;
+    p.out0_c = p.N;
+    p.ntile[0] = (p.bd[0] + 3) / 4; p.ntile[1] = (p.bd[1] + 3) / 4; p.ntile[2] = (p.bd[2] + 15) / 16;
+    const int tiles_img = p.ntile[0] * p.ntile[1] * p.ntile[2];
+    {
+        // tiles per workgroup: a divisor of the tiles of one image (the statistics partials of a workgroup belong to
+        // one image), aiming at about three workgroups per CU
+        static const int div_env = getenv("MI_C3K16_WGS") ? atoi(getenv("MI_C3K16_WGS")) : 0;
+        const long long wgs1 = (long long)p.nb * tiles_img * (p.N / 16);
+        int want = (int)(wgs1 / (div_env > 0 ? div_env : 768));
+        if (want > 16) want = 16;
+        if (want < 1) want = 1;
+        int tpw = 1;
+        for (int t = 1; t <= want; ++t) if (tiles_img % t == 0) tpw = t;
+        p.tpw = tpw;
+    }
+    dim3 grid(p.nb * tiles_img / p.tpw, p.N / 16, 1);
+    hipLaunchKernelGGL(conv3d_k16_kernel, grid, dim3(256), (size_t)2 * C3_PBYTES, st, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { mi_set_error(std::string("conv3d k16 launch: ") + hipGetErrorString(e)); return -2; }
+    return 0;
+}
+
 template <class TR, int NFRAG, int KS, bool WRES>
 int launch_conv2d_t(const IgemmParams& pin, hipStream_t st) {
     IgemmParams p = pin;
@@ -1324,3 +1486,21 @@ int launch_conv2d_dma(int dtype, const IgemmParams& p, hipStream_t st) {
     mi_set_error("launch_conv2d_dma: no kernel variant");
     return -1;
 }
+
+// 3-D layers conv3d_k16_kernel serves: bf16, 16 contraction channels from one source, 27 taps in patch order, unit
+// stride, one destination, no contraction split.
+bool conv3d_k16_applicable(int dtype, const IgemmParams& p) {
+    static const bool off = getenv("MI_NO_CONV3D_K16") != nullptr;
+    if (off || !dtype || p.K != 16 || p.in0_c < 16 || p.N % 16 || p.N > 32 || p.sa != 1 || p.so != 1 || p.nphase != 1) return false;
+    if (p.id[0] < 2 || p.phase_start[1] != 27 || p.out1 || p.ksplit > 1) return false;
+    for (int d = 0; d < 3; ++d)
+        if (p.omin[d] != -1 || p.id[d] != p.bd[d] || p.od[d] != p.bd[d]) return false;
+    for (int t = 0; t < 27; ++t)
+        if (p.tap_off[t] != ((t / 9) * p.pd[1] + (t / 3) % 3) * p.pd[2] + t % 3) return false;
+    // 32-bit byte offsets inside a patch and 32-bit pixel indices
+    if ((long long)8 * p.id[1] * p.id[2] * p.in0_pitch * 2 >= (1ll << 31)) return false;
+    if ((long long)p.nb * p.id[0] * p.id[1] * p.id[2] >= (1ll << 31)) return false;
+    return true;
+}
+
+int launch_conv3d_k16(const IgemmParams& p, hipStream_t st) { return launch_conv3d_k16_t(p, st); }

@@ -251,6 +251,8 @@ struct Builder {
         snprintf(kb, sizeof(kb), "igemm_kernel<%s,%d,%d>", u.dt ? "BF16" : "F32", cps, nfrag);
         if (conv2d_dma_enabled() && conv2d_dma_applicable(u.dt, p))
             conv2d_dma_label(u.dt, p, kb, sizeof(kb));
+        else if (conv2d_dma_enabled() && conv3d_k16_applicable(u.dt, p))
+            snprintf(kb, sizeof(kb), "conv3d_k16_kernel");
         else
             igemm_dma_label(u.dt, p, kb, sizeof(kb));
         s.kernel = kb;
@@ -267,7 +269,10 @@ struct Builder {
             long long wgs = 0; int nkc = 1;
             igemm_parallelism(u.dt, p, &wgs, &nkc);
             int ks = 1;
-            if (!getenv("MI_NO_KSPLIT") && wgs < 256 && nkc >= 2 && N % 4 == 0 && N / 4 <= 256) {
+            // a forward 1 x 1 (x 1) convolution is a handful of contraction steps: splitting it buys a second launch
+            // and nothing else (in the backward pass its finishing pass carries the norm backward, so it stays split)
+            const bool one_tap_fwd = *ntaps_out == 1 && &list == &u.fwd && !getenv("MI_SPLIT_1TAP_FWD");
+            if (!getenv("MI_NO_KSPLIT") && !one_tap_fwd && wgs < 256 && nkc >= 2 && N % 4 == 0 && N / 4 <= 256) {
                 // workgroups aimed at: 256 in 3-D; 64 in 2-D, where a split layer leaves the asynchronously staged
                 // kernels for the generic one and only the smallest layers gain (measured: batch 8 x 256^2 0.943 ->
                 // 0.881 ms per step at 64 instead of 512, 96^3 patches 1.791 -> 1.773 ms at 256)

@@ -1055,6 +1055,7 @@ int launch_igemm(int dtype, const IgemmParams& p, hipStream_t st) {
         MI_CHECK(!p.out1 || (p.out0_c % 16 == 0 && p.out0_c > 0 && p.out0_c < p.N), "first-destination channel count must be a multiple of 16");
         return launch_conv2d_dma(dtype, p, st);
     }
+    if (conv2d_dma_enabled() && conv3d_k16_applicable(dtype, p)) return launch_conv3d_k16(p, st);
     if (igemm_dma_applicable(dtype, p)) return launch_igemm_dma(dtype, p, st);
     int cps, nfrag;
     igemm_config(dtype, p, &cps, &nfrag);

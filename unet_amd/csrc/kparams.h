@@ -166,6 +166,8 @@ int launch_wgrad(int dtype, const WgradParams& p, hipStream_t st);
 bool conv2d_dma_applicable(int dtype, const IgemmParams& p);   // conv2d.hip: asynchronously staged 2-D kernels
 int launch_conv2d_dma(int dtype, const IgemmParams& p, hipStream_t st);
 bool conv2d_dma_enabled();
+bool conv3d_k16_applicable(int dtype, const IgemmParams& p);   // conv2d.hip: 3-D 3 x 3 x 3 layers with 16 bf16 contraction channels
+int launch_conv3d_k16(const IgemmParams& p, hipStream_t st);
 bool igemm_dma_applicable(int dtype, const IgemmParams& p);   // igemm_dma.hip: asynchronously staged kernel for any tile geometry (unit gather stride)
 bool igemm_dma_config(int dtype, const IgemmParams& p, int* cps, int* nfrag);
 int launch_igemm_dma(int dtype, const IgemmParams& p, hipStream_t st);
