@@ -218,3 +218,11 @@ inline hipError_t mi_func_set_lds(const void* kern, int bytes) {
             return -2;                                                                   \
         }                                                                                \
     } while (0)
+
+// "This kernel has started": one relaxed system-scope store by the first workgroup.  A side stream waiting on the word
+// (hipStreamWaitValue32) is released without any packet on this kernel's own stream; what it then reads was written by
+// kernels that completed, caches released, before this one could start.
+__device__ __forceinline__ void signal_start(unsigned* flag, unsigned val) {
+    if (flag && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
+        __hip_atomic_store(flag, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}

@@ -227,6 +227,7 @@ __device__ __forceinline__ void wait_vmcnt_c() {
 // up to three kernel rows: the MFMA share of the issued instructions decides the speed of this kernel.
 template <class TR, int NFRAG, int KS, bool WRES>
 __global__ __launch_bounds__(256, 2) void conv2d_dma_kernel(const IgemmParams p) {
+    signal_start(p.start_flag, p.start_val);
     constexpr int ESZ = TR::ESZ;
     constexpr int KCE = 64 / ESZ;                  // contraction elements per 64-byte chunk row
     constexpr int NT = NFRAG * 16;
@@ -446,6 +447,7 @@ __host__ __device__ constexpr int ph_dx(int t) { return (t == 1 || t == 5 || t =
 
 template <class TR, int NFRAG, bool ADD>     // ADD: the layer has an addend (a kernel of its own: the other keeps the shorter epilogue)
 __global__ __launch_bounds__(256, 2) void conv2d_phase_kernel(const IgemmParams p) {
+    signal_start(p.start_flag, p.start_val);
     constexpr int ESZ = TR::ESZ;
     constexpr int KCE = 64 / ESZ;
     constexpr int NT = NFRAG * 16;
@@ -647,6 +649,7 @@ __host__ __device__ constexpr int s2_tap(int c, int i) {     // i-th tap of comp
 }
 template <class TR, int NFRAG, bool WRES>
 __global__ __launch_bounds__(256, 2) void conv2d_s2_kernel(const IgemmParams p) {
+    signal_start(p.start_flag, p.start_val);
     constexpr int ESZ = TR::ESZ;
     constexpr int KCE = 64 / ESZ;
     constexpr int NT = NFRAG * 16;
@@ -853,6 +856,7 @@ __host__ __device__ constexpr int k16_tap(int step, int hi) { return 2 * step + 
 
 template <int NFRAG>
 __global__ __launch_bounds__(256, 2) void conv2d_k16_kernel(const IgemmParams p) {
+    signal_start(p.start_flag, p.start_val);
     using TR = BF16;
     constexpr int ESZ = 2;
     constexpr int NT = NFRAG * 16;
@@ -1009,6 +1013,7 @@ __host__ __device__ constexpr int s2k16_ix(int step, int hi) { return (step == 1
 
 template <int NFRAG>
 __global__ __launch_bounds__(256, 2) void conv2d_s2k16_kernel(const IgemmParams p) {
+    signal_start(p.start_flag, p.start_val);
     using TR = BF16;
     constexpr int ESZ = 2;
     constexpr int NT = NFRAG * 16;
@@ -1177,6 +1182,7 @@ constexpr int C3_PBYTES = C3_NIP * 1024;
 constexpr int C3_NUP = (C3_NIP + 3) / 4;
 
 __global__ __launch_bounds__(256, 2) void conv3d_k16_kernel(const IgemmParams p) {
+    signal_start(p.start_flag, p.start_val);
     using TR = BF16;
     constexpr int ESZ = 2;
     extern __shared__ __attribute__((aligned(1024))) char smem[];

@@ -16,6 +16,7 @@ namespace {
 
 template <class TR, int CPS, int NFRAG>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
+    signal_start(p.start_flag, p.start_val);
     constexpr int ESZ = TR::ESZ;
     constexpr int KCB = CPS * 16;    // contraction bytes per pixel per stage
     constexpr int KCE = KCB / ESZ;   // ... in elements
@@ -168,6 +169,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 // two destinations, plus the per-(image, channel) statistics.  Thread = (pixel row, four channels).
 template <class TR>
 __global__ __launch_bounds__(256) void ksplit_finish_kernel(const IgemmParams p, int npix_img) {
+    signal_start(p.start_flag, p.start_val);
     constexpr int ESZ = TR::ESZ;
     extern __shared__ __attribute__((aligned(16))) float sm[];   // [256][8] statistics partials
     const int img = blockIdx.y;
@@ -237,6 +239,7 @@ __global__ __launch_bounds__(256) void ksplit_finish_kernel(const IgemmParams p,
 // (two / one workgroup per CU), under a cap it fits 144 / 218 without spilling (three / two).
 template <class TR, int CPS, int NFRAG, int KS, int SA, bool PHL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHL ? (NFRAG == 1 ? 3 : 2) : 1))) void igemm2d_kernel(const IgemmParams p) {
+    signal_start(p.start_flag, p.start_val);
     constexpr int ESZ = TR::ESZ;
     constexpr int KCB = CPS * 16, KCE = KCB / ESZ, PITCH = KCB + 16, NT = NFRAG * 16;
     // weight image: 32-byte rows are stored without padding, the two 16-byte halves of a row swapped in every
@@ -881,6 +884,39 @@ template <class TR>
 __device__ __forceinline__ void pack_body(const PackDesc& d, int blk, int nblk) {
     const int pairs = d.N * d.K;
     typename TR::elem* dst = reinterpret_cast<typename TR::elem*>(d.dst);
+    // Tiles of 16 x 16 (n, k) pairs through LDS when the source is a dense [n][k][taps] or [k][n][taps] tensor: the
+    // 16 pairs of a run along the source's inner dimension are one contiguous piece of 16 * taps floats, read with
+    // consecutive lanes; each thread then takes the taps of its own pair from LDS (run pitch and tap count odd: no
+    // bank conflicts) and stores them with k fastest.  One pair per thread straight from global memory reads four
+    // bytes per lane at a stride of `taps` floats, or of a whole source row, in every load.
+    const int KK = d.sn < d.sk ? d.sn : d.sk;
+    const bool inner_k = d.sk == KK && d.sn == d.K * KK, inner_n = !inner_k && d.sn == KK && d.sk == d.N * KK;
+    if ((inner_k || inner_n) && d.N % 16 == 0 && d.K % 16 == 0 && KK >= 1 && KK <= 27) {
+        __shared__ float tile[16 * (16 * 27 + 1)];
+        const int run_len = 16 * KK, RP = run_len + 1;
+        const int tk = d.K / 16, ntile = (d.N / 16) * tk;
+        const int kl = threadIdx.x & 15, nl = threadIdx.x >> 4;
+        const float* pv = tile + (inner_k ? nl * RP + kl * KK : kl * RP + nl * KK);
+        const size_t ot = (size_t)d.Ntot * d.Ktot;
+        for (int tix = blk; tix < ntile; tix += nblk) {
+            const int n0 = (tix / tk) * 16, k0 = (tix % tk) * 16;
+            __syncthreads();
+            for (int e = threadIdx.x; e < 16 * run_len; e += 256) {
+                const int run = e / run_len, r = e - run * run_len;
+                const float* src = inner_k ? d.src + (size_t)(n0 + run) * d.sn + (size_t)k0 * KK + r
+                                           : d.src + (size_t)(k0 + run) * d.sk + (size_t)n0 * KK + r;
+                tile[run * RP + r] = *src;
+            }
+            __syncthreads();
+            const size_t o0 = (size_t)(d.n_off + n0 + nl) * d.Ktot + d.k_off + k0 + kl;
+            for (int t = 0; t < d.ntaps; ++t) {
+                const float v = pv[d.kidx[t]];
+                if (TR::ESZ == 2) dst[o0 + (size_t)t * ot] = f32_to_bf16(v);
+                else reinterpret_cast<float*>(dst)[o0 + (size_t)t * ot] = v;
+            }
+        }
+        return;
+    }
     for (int i = blk * 256 + threadIdx.x; i < pairs; i += nblk * 256) {
         const int n = i / d.K; const int k = i - n * d.K;
         const float* src = d.src + (size_t)n * d.sn + (size_t)k * d.sk;

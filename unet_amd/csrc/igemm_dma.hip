@@ -41,6 +41,7 @@ constexpr int DMA_MAXUW = 9;    // weight wave-instructions per wave: at most 36
 
 template <class TR, int CPS, int NFRAG>
 __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmParams p) {
+    signal_start(p.start_flag, p.start_val);
     constexpr int ESZ = TR::ESZ;
     constexpr int ROWB = CPS * 16;       // bytes of a pixel row / weight row in LDS = one contraction chunk
     constexpr int KCE = ROWB / ESZ;      // contraction elements per chunk

@@ -49,6 +49,7 @@ struct IgemmParams {
     int comp_start[9];
     int ctap_off[MI_MAX_TAPS];
     int cpd[3];
+    unsigned* start_flag; unsigned start_val;   // not null: the first workgroup stores start_val there as the kernel starts (see NormParams)
 };
 
 // Weight-gradient launch: partial[slab][tap][f][s] = sum_{base pixels of the slab}

@@ -11,14 +11,6 @@
 
 namespace {
 
-// "This kernel has started": one relaxed system-scope store by the first workgroup.  A side stream waiting on the word
-// (hipStreamWaitValue32) is released without any packet on this kernel's own stream; what it then reads was written by
-// kernels that completed, caches released, before this one could start.
-__device__ __forceinline__ void signal_start(unsigned* flag, unsigned val) {
-    if (flag && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
-        __hip_atomic_store(flag, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
 // mean / rstd of every channel of image `img` into LDS (2 floats per channel); the sums are fp64
 __device__ __forceinline__ void load_moments(const double* stats, int img, int c, int npix, float eps, float* sm) {
     for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
