@@ -274,11 +274,12 @@ struct Builder {
             // and nothing else (in the backward pass its finishing pass carries the norm backward, so it stays split)
             const bool one_tap_fwd = *ntaps_out == 1 && &list == &u.fwd && !getenv("MI_SPLIT_1TAP_FWD");
             if (!getenv("MI_NO_KSPLIT") && !one_tap_fwd && wgs < 256 && nkc >= 2 && N % 4 == 0 && N / 4 <= 256) {
-                // workgroups aimed at: 256 in 3-D; 64 in 2-D, where a split layer leaves the asynchronously staged
+                // workgroups aimed at: 512 in 3-D; 64 in 2-D, where a split layer leaves the asynchronously staged
                 // kernels for the generic one and only the smallest layers gain (measured: batch 8 x 256^2 0.943 ->
-                // 0.881 ms per step at 64 instead of 512, 96^3 patches 1.791 -> 1.773 ms at 256)
+                // 0.881 ms per step at 64 instead of 512; 96^3 patches, with the finishing pass inside the norm
+                // launches: 1.700 / 1.578 / 1.539 / 1.524 / 1.526 ms at 64 / 128 / 256 / 512 / 1024)
                 static const int kst_env = getenv("MI_KSPLIT_TARGET") ? atoi(getenv("MI_KSPLIT_TARGET")) : 0;
-                const int kst = kst_env > 0 ? kst_env : (u.nd == 3 ? 256 : 64);
+                const int kst = kst_env > 0 ? kst_env : (u.nd == 3 ? 512 : 64);
                 ks = (int)((kst + wgs - 1) / wgs);
                 if (ks > nkc) ks = nkc;
                 if (ks > 8) ks = 8;
@@ -1165,8 +1166,13 @@ unsigned fork_event_flags() {
     return hipEventDisableTiming | (sys ? 0u : (unsigned)hipEventDisableSystemFence);
 }
 
+// Buffers of the later parts of a training step that must start at zero (loss sums, backward statistics): a forward
+// pass that forks the side stream for the weight packing clears them there, off the main chain (each memset on the
+// main stream is a ~5 us link of it); `done` tells the caller whether that happened.
+struct PreClear { void* ptr[2]; size_t bytes[2]; bool done; };
+
 int run_list(mi_unet& u, std::vector<Step>& list, int backward, int bucket, char* const* bases, int training, uint64_t seed,
-             hipStream_t st, hipStream_t join_to = nullptr) {
+             hipStream_t st, hipStream_t join_to = nullptr, PreClear* pre = nullptr, bool skip_memset = false) {
     // A second stream runs work that is off the critical chain: in the backward pass the weight gradients and
     // the slab reductions (joined at the end of the call), in the forward pass the weight packing (joined in
     // front of the first kernel that reads packed weights).  Timing runs stay on one stream.
@@ -1316,6 +1322,7 @@ int run_list(mi_unet& u, std::vector<Step>& list, int backward, int bucket, char
     for (size_t i = 0; i < list.size(); ++i) {
         Step& s = list[i];
         if (bucket >= 0 && s.bucket != bucket) continue;
+        if (skip_memset && s.kind == K_MEMSET) continue;
         if (side && backward && (is_wgrad_kind(s.kind) || s.kind == K_REDUCE)) {
             if (ndeferred == 16) { if (int r = flush_by_event()) return r; }
             deferred[ndeferred++] = &s;
@@ -1333,6 +1340,11 @@ int run_list(mi_unet& u, std::vector<Step>& list, int backward, int bucket, char
             if (!pack_first_pending && !pack_first_done) {
                 MI_HIP(hipEventRecord(u.pack_ev, u.side));
                 pack_first_pending = true;
+            } else if (pre && !pre->done) {
+                // behind the second packing launch: the first deep layer's join covers these too
+                for (int k = 0; k < 2; ++k)
+                    if (pre->ptr[k] && pre->bytes[k]) MI_HIP(hipMemsetAsync(pre->ptr[k], 0, pre->bytes[k], u.side));
+                pre->done = true;
             }
             pending = true;
         } else {
@@ -1510,8 +1522,22 @@ static int train_step_body(mi_unet* u, const mi_train_step_args* a, void* stream
     char* bases[B_NBASE] = {nullptr};
     bases[B_ARENA] = (char*)a->workspace; bases[B_PARAMS] = (char*)a->params; bases[B_XIN] = (char*)a->x;
     bases[B_LOGITS] = (char*)a->logits;
-    if (int r = run_list(*u, u->fwd, 0, -1, bases, 1, a->seed, st)) return r;
+    // loss sums and backward statistics are zeroed on the side stream during the forward pass when it has one
+    PreClear pre; memset(&pre, 0, sizeof(pre));
+    static const bool no_pre = getenv("MI_NO_PRECLEAR") != nullptr;
+    if (!no_pre) {
+        pre.ptr[0] = a->loss_sums; pre.bytes[0] = (size_t)u->nb * 4 * sizeof(double);
+        int nms = 0;
+        for (Step& s : u->bwd)
+            if (s.kind == K_MEMSET) {
+                MemsetArgs m = resolve(s, s.ms, bases);
+                pre.ptr[1] = m.ptr; pre.bytes[1] = m.bytes; ++nms;
+            }
+        if (nms != 1) { pre.ptr[0] = pre.ptr[1] = nullptr; }       // unexpected plan shape: the ordinary memsets stay
+    }
+    if (int r = run_list(*u, u->fwd, 0, -1, bases, 1, a->seed, st, nullptr, pre.ptr[0] ? &pre : nullptr)) return r;
     LossParams p; memset(&p, 0, sizeof(p));
+    p.sums_cleared = pre.done ? 1 : 0;
     p.logits = a->logits; p.target = a->target; p.tdtype = a->target_dtype; p.fold2 = a->fold2; p.sums = a->loss_sums;
     p.loss = a->loss; p.loss_accum = a->loss_accum; p.nb = u->nb; p.npix = (int)npix;
     p.smooth_nr = a->smooth_nr; p.smooth_dr = a->smooth_dr; p.lambda_dice = a->lambda_dice; p.lambda_ce = a->lambda_ce;
@@ -1519,7 +1545,7 @@ static int train_step_body(mi_unet* u, const mi_train_step_args* a, void* stream
     p.dlogits = a->dlogits; p.gout = nullptr; p.gscale = 1.0f;
     if (int r = launch_loss_bwd(p, st)) return r;
     bases[B_LOGITS] = nullptr; bases[B_GRADS] = (char*)a->grads; bases[B_DLOGITS] = (char*)a->dlogits;
-    if (int r = run_list(*u, u->bwd, 1, -1, bases, 1, a->seed, st)) return r;
+    if (int r = run_list(*u, u->bwd, 1, -1, bases, 1, a->seed, st, nullptr, nullptr, pre.done)) return r;
     if (a->do_adamw)
         return mi_adamw_step(a->params, a->grads, a->exp_avg, a->exp_avg_sq, u->nfloats, a->lr, a->beta1, a->beta2, a->eps,
                              a->weight_decay, a->step, a->grad_scale, stream);

@@ -281,7 +281,7 @@ static bool loss_v4(const LossParams& p) {
 
 // sums ([nb][4] doubles) is zeroed here, then filled; loss[0] is written; loss_accum (optional) is accumulated.
 int launch_loss_fwd(const LossParams& p, hipStream_t st) {
-    MI_HIP(hipMemsetAsync(p.sums, 0, (size_t)p.nb * 4 * sizeof(double), st));
+    if (!p.sums_cleared) MI_HIP(hipMemsetAsync(p.sums, 0, (size_t)p.nb * 4 * sizeof(double), st));
     if (loss_v4(p)) hipLaunchKernelGGL(loss_reduce_kernel<4>, dim3(grid_for(p.npix, 2048, 128), p.nb), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(loss_reduce_kernel<1>, dim3(grid_for(p.npix, 2048, 128), p.nb), dim3(256), 0, st, p);
     if (int r = check_launch("loss_reduce")) return r;
