@@ -1538,6 +1538,8 @@ static int train_step_body(mi_unet* u, const mi_train_step_args* a, void* stream
     if (int r = run_list(*u, u->fwd, 0, -1, bases, 1, a->seed, st, nullptr, pre.ptr[0] ? &pre : nullptr)) return r;
     LossParams p; memset(&p, 0, sizeof(p));
     p.sums_cleared = pre.done ? 1 : 0;
+    static const bool no_fuse = getenv("MI_NO_LOSS_FUSE") != nullptr;
+    p.fuse_finalize = no_fuse ? 0 : 1;
     p.logits = a->logits; p.target = a->target; p.tdtype = a->target_dtype; p.fold2 = a->fold2; p.sums = a->loss_sums;
     p.loss = a->loss; p.loss_accum = a->loss_accum; p.nb = u->nb; p.npix = (int)npix;
     p.smooth_nr = a->smooth_nr; p.smooth_dr = a->smooth_dr; p.lambda_dice = a->lambda_dice; p.lambda_ce = a->lambda_ce;

@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const LossParams p) {
 
 // loss = lambda_dice * mean_b(1 - (2I+snr)/(P+T+sdr)) + lambda_ce * sum_b(bce) / (nb*npix)
 // one wave: lane l takes samples l, l + 64, ..., the lanes are combined by a fixed butterfly
-__global__ void loss_finalize_kernel(const LossParams p) {
+// loss value from the per-sample sums: lanes 0..63 of one wave
+__device__ __forceinline__ void loss_finalize_body(const LossParams& p) {
     double dice = 0.0, ce = 0.0;
     for (int b = threadIdx.x; b < p.nb; b += 64) {
         const double* s = p.sums + b * 4;
@@ -101,6 +102,7 @@ __global__ void loss_finalize_kernel(const LossParams p) {
     p.loss[0] = l;
     if (p.loss_accum) p.loss_accum[0] += l;
 }
+__global__ void loss_finalize_kernel(const LossParams p) { loss_finalize_body(p); }
 
 // dz = g * [ lambda_dice/nb * (-2 t D + (2I+snr)) / D^2 * s(1-s) + lambda_ce * (s - t)/(nb*npix) ],  D = P+T+sdr
 template <int W>
@@ -128,6 +130,8 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const LossParams p) {
         if constexpr (W == 4) *reinterpret_cast<float4*>(p.dlogits + base + (size_t)g * W) = make_float4(o[0], o[1], o[2], o[3]);
         else p.dlogits[base + (size_t)g] = o[0];
     }
+    // one launch fewer on a training step's chain: the first wave of the grid also turns the sums into the loss value
+    if (p.fuse_finalize && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) loss_finalize_body(p);
 }
 
 // counts[b] = { tp, fp, fn, tn } as 64-bit integers; prediction = (pred >= thresh), truth = (label == 1)
@@ -285,6 +289,7 @@ int launch_loss_fwd(const LossParams& p, hipStream_t st) {
     if (loss_v4(p)) hipLaunchKernelGGL(loss_reduce_kernel<4>, dim3(grid_for(p.npix, 2048, 128), p.nb), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(loss_reduce_kernel<1>, dim3(grid_for(p.npix, 2048, 128), p.nb), dim3(256), 0, st, p);
     if (int r = check_launch("loss_reduce")) return r;
+    if (p.fuse_finalize) return 0;        // launch_loss_bwd with the same parameters writes the loss value
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, p);
     return check_launch("loss_finalize");
 }

@@ -7,6 +7,7 @@ struct LossParams {
     const float* logits;        // [nb][npix] fp32 (one channel)
     const void* target; int tdtype; int fold2;   // fold2: label value 2 counts as 1
     double* sums;               // [nb][4] = { sum p*t, sum p, sum t, sum bce } (fp64 accumulators)
+    int fuse_finalize;          // the loss value is written by the backward launch (one-call training step) instead of a launch of its own
     int sums_cleared;           // forward: the caller has zeroed `sums` already (launch_loss_fwd then enqueues no memset)
     float* loss; float* loss_accum;
     float* dlogits; const float* gout; float gscale;
