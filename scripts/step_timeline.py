@@ -1,11 +1,12 @@
-"""Prints every kernel of one training step (between the last two AdamW launches) from a rocprofv3 kernel trace, with
+"""Prints every kernel of one training step (from one loss reduction to the next: a backward pass, the optimizer, the
+next forward pass) from a rocprofv3 kernel trace, with
 start / end in microseconds from the step's first kernel and its queue, then the busy time per queue and the time in
 which only one queue runs:  python scripts/step_timeline.py <kernel_trace.csv>"""
 import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1]))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "adamw" in r["Kernel_Name"]]
-a, b = idx[-2] + 1, idx[-1] + 1
+idx = [i for i, r in enumerate(rows) if "loss_reduce" in r["Kernel_Name"]]
+a, b = idx[-2], idx[-1]
 step = rows[a:b]
 t0 = int(step[0]["Start_Timestamp"])
 busy = {}
