@@ -142,11 +142,14 @@ def test_fused_step_equals_autograd_step_fp32(dev):
     assert float((ma.flat_parameters() - mb.flat_parameters()).abs().max()) < 2.5e-3
 
 
-@pytest.mark.parametrize("dt,drop", [(torch.float32, 0.0), (torch.bfloat16, 0.1)], ids=["fp32", "bf16_dropout"])
-def test_one_call_step_equals_the_split_calls_bit_for_bit(dev, dt, drop):
+@pytest.mark.parametrize("dt,drop,nb,size", [(torch.float32, 0.0, 4, 128), (torch.bfloat16, 0.1, 4, 128), (torch.bfloat16, 0.1, 16, 512)],
+                         ids=["fp32", "bf16_dropout", "bf16_dropout_large_batch"])
+def test_one_call_step_equals_the_split_calls_bit_for_bit(dev, dt, drop, nb, size):
     """mi_unet_train_step (one library call per step) against forward + loss + backward + AdamW as separate calls:
-    same kernels in the same order, so parameters, gradients, moments and the loss sum agree exactly over three steps."""
-    x, t = _batch(4, 128, dev)
+    same kernels in the same order, so parameters, gradients, moments and the loss sum agree exactly over three steps.
+    The one-call step clears the loss sums and backward statistics beside the forward pass, lets the loss backward
+    launch write the loss value and, on a large batch, runs AdamW bucket by bucket behind each bucket's reduction."""
+    x, t = _batch(nb, size, dev)
 
     def run(split):
         torch.manual_seed(4)

@@ -84,6 +84,10 @@ class BucketedAllReduce:
         if not self._works and self._comm_stream is None:
             return
         if self._comm_stream is not None:       # also without collectives: the stream may carry waits the caller handed it
+            # a backend that completes on the host blocks this thread next: hand the device everything enqueued so far
+            if not torch.cuda.is_current_stream_capturing():
+                torch.cuda.current_stream(self.flat.device).query()
+                self._comm_stream.query()
             with torch.cuda.stream(self._comm_stream):
                 for w in self._works:
                     w.wait()              # RCCL: the communication stream waits; host-side backends: the host does
