@@ -3,8 +3,8 @@
     python dp_child.py RANK WORLD PORT OUT.pt
 
 Trains three steps on this rank's shard of a fixed batch with the bucketed, overlapped gradient exchange of
-``unet_amd.Trainer`` (gloo all-reduce on device tensors: all ranks share the one visible GPU, where RCCL refuses two
-ranks) and saves its parameters and the averaged gradient of the first step.  WORLD = 1 is the full-batch run the
+``unet_amd.Trainer`` (gloo all-reduce, staged through pinned host memory by the reducer: all ranks share the one visible
+GPU, where RCCL refuses two ranks) and saves its parameters and the averaged gradient of the first step.  WORLD = 1 is the full-batch run the
 ranks are compared with.  A watchdog ends the process after 100 s: a stuck collective must not outlive the test."""
 import faulthandler
 import os

@@ -2,8 +2,9 @@
 reference/train.py:109-119 sharded by batch): two fresh processes, both on the one visible GPU, train on the halves
 of a batch through ``unet_amd.Trainer`` - bucket-by-bucket backward, one asynchronous all-reduce per bucket on the
 communication stream while the next bucket computes, AdamW behind the last one - and must follow a one-process run on
-the whole batch.  The exchange is gloo on device tensors (RCCL refuses two ranks on one device; the RCCL bucket path
-itself runs in tests/test_dp_rccl_gpu.py): a correctness rehearsal of the multi-rank step, not a model of its speed."""
+the whole batch.  The exchange is gloo (RCCL refuses two ranks on one device; the RCCL bucket path itself runs in
+tests/test_dp_rccl_gpu.py), for which the reducer stages each bucket through pinned host memory: a correctness
+rehearsal of the multi-rank step, not a model of its speed."""
 import os
 import socket
 import subprocess

@@ -1402,16 +1402,7 @@ int run_list(mi_unet& u, std::vector<Step>& list, int backward, int bucket, char
     };
     if (int r = body()) return r;
     if (int r = run_late()) return r;
-    if (join_to && side) {      // also when nothing is pending: earlier calls' work may still run
-        if (int r = join_other(join_to)) return r;
-        // The caller may block on the host next (a collective that completes on the host, such as gloo on device
-        // tensors) with nothing further enqueued on the side stream: a query makes the runtime hand everything it
-        // still holds for that stream to the device.  Not under capture (a query is not a capturable operation).
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) (void)hipStreamQuery(u.side);
-        (void)hipGetLastError();
-        return 0;
-    }
+    if (join_to && side) return join_other(join_to);       // also when nothing is pending: earlier calls' work may still run
     if (pending) { if (int r = join()) return r; }
     return 0;
 }

@@ -58,6 +58,13 @@ class BucketedAllReduce:
         self.force = bool(force) and dist.is_initialized()
         self._works: List = []
         self._comm_stream = torch.cuda.Stream(flat.device) if flat.is_cuda else None
+        # A backend that reduces on the host (gloo) gets host tensors: each bucket is copied to pinned memory on the
+        # communication stream as soon as it is complete, reduced there by wait(), and copied back.  torch's own gloo
+        # path for device tensors does the same staging from worker threads of its own; two ranks sharing one GPU
+        # hung in it now and then (both hosts in wait(), no kernel of ours pending).
+        self._staged = bool(flat.is_cuda and dist.is_initialized() and dist.get_backend(group) == "gloo")
+        self._pinned: List = []
+        self._copied: List = []
 
     @property
     def comm_stream(self):
@@ -71,7 +78,20 @@ class BucketedAllReduce:
         if c == 0:
             return
         view = self.flat[o:o + c]
-        if self._comm_stream is not None:
+        if self._staged:
+            while len(self._pinned) <= i:
+                self._pinned.append(None)
+            if self._pinned[i] is None or self._pinned[i].numel() != c:
+                self._pinned[i] = torch.empty(c, dtype=self.flat.dtype, pin_memory=True)
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(self.flat.device))
+            with torch.cuda.stream(self._comm_stream):
+                self._comm_stream.wait_event(ready)
+                self._pinned[i].copy_(view, non_blocking=True)
+                copied = torch.cuda.Event()
+                copied.record(self._comm_stream)
+            self._copied.append((i, copied))
+        elif self._comm_stream is not None:
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream(self.flat.device))
             with torch.cuda.stream(self._comm_stream):
@@ -83,11 +103,20 @@ class BucketedAllReduce:
     def wait(self) -> None:
         if not self._works and self._comm_stream is None:
             return
+        if self._staged:
+            # in launch order: the later buckets are still being computed while the first ones are reduced
+            for i, copied in self._copied:
+                copied.synchronize()
+                dist.all_reduce(self._pinned[i], op=dist.ReduceOp.SUM, group=self.group)
+                o, c = self.buckets[i]
+                with torch.cuda.stream(self._comm_stream):
+                    self.flat[o:o + c].copy_(self._pinned[i], non_blocking=True)
+            self._copied = []
+            done = torch.cuda.Event()
+            done.record(self._comm_stream)
+            torch.cuda.current_stream(self.flat.device).wait_event(done)
+            return
         if self._comm_stream is not None:       # also without collectives: the stream may carry waits the caller handed it
-            # a backend that completes on the host blocks this thread next: hand the device everything enqueued so far
-            if not torch.cuda.is_current_stream_capturing():
-                torch.cuda.current_stream(self.flat.device).query()
-                self._comm_stream.query()
             with torch.cuda.stream(self._comm_stream):
                 for w in self._works:
                     w.wait()              # RCCL: the communication stream waits; host-side backends: the host does
