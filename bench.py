@@ -430,6 +430,16 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
         nwin = len(unet_amd.window_starts([max(args.size, args.roi)] * args.dims, [args.roi] * args.dims, 0.25))
+        if rank == 0 and world == 1 and os.environ.get("BENCH_LAYERS"):
+            # per-launch table of the forward pass of the largest window batch (every launch bracketed by HIP events)
+            plan = max(model._plans.values(), key=lambda p: p.batch)
+            profiled(plan, 3, lambda: ev.slice_dice(x, t))
+            log("[bench] per-launch (layer) averages:")
+            for st in plan.steps(False):
+                if st["launches"]:
+                    us = 1e3 * st["total_ms"] / st["launches"]
+                    tf = st["work"] / (us * 1e-6) / 1e12 if st["work_is_flops"] else 0.0
+                    log(f"  fwd {st['layer']:48s} {st['kernel']:34s} {us:9.2f} us {tf:8.1f} TF/s {st['bytes'] / (us * 1e-6) / 1e9:9.1f} GB/s")
         if rank == 0:
             print(json.dumps({
                 "metric": "inference slices/sec (whole node), sliding window", "value": round(world * args.batch * args.steps / elapsed, 2),
@@ -558,7 +568,7 @@ def main():
                         us = 1e3 * s["total_ms"] / s["launches"]
                         tf = s["work"] / (us * 1e-6) / 1e12 if s["work_is_flops"] else 0.0
                         log(f"  {'bwd' if backward else 'fwd'} {s['layer']:48s} {s['kernel']:34s} {us:9.2f} us {tf:8.1f} TF/s {s['bytes'] / (us * 1e-6) / 1e9:9.1f} GB/s")
-        conv = {k: r for k, r in rows.items() if r["flops"] > 0 and ("igemm" in k or "conv2d_" in k or "wgrad_kernel" in k or "wgrad_thick" in k or "wgrad_thin" in k)}
+        conv = {k: r for k, r in rows.items() if r["flops"] > 0 and ("igemm" in k or "conv2d_" in k or "conv3d_" in k or "wgrad_kernel" in k or "wgrad_thick" in k or "wgrad_thin" in k)}
         conv_s = sum(r["ms"] for r in conv.values()) / 1e3
         conv_f = sum(r["flops"] for r in conv.values())
         out["mfma_util"] = round(conv_f / conv_s / MFMA_BF16_PEAK, 4) if conv_s else None
