@@ -49,6 +49,7 @@ CASES = [
     (3, (6, 10, 20), 16, 16, 3, 1, False),    # 3-D, 16 contraction channels (bf16: tap pairs, fragments shared over kernel rows): ragged in z, y and x
     (3, (9, 5, 33), 16, 32, 3, 1, False),     # the same with two channel blocks and odd extents
     (3, (4, 8, 12), 32, 64, 3, 1, False),
+    (3, (9, 6, 20), 32, 32, 3, 1, False),     # 3-D, 32 contraction channels: 16 output channels per workgroup, ragged tiles
     (3, (8, 8, 8), 16, 64, 3, 2, False),
     (3, (4, 4, 4), 64, 16, 3, 2, True),
     (3, (4, 4, 4), 32, 64, 1, 1, False),
