@@ -91,6 +91,25 @@ int mi_unet_backward(mi_unet* u, const float* params, const float* x, const floa
 int mi_unet_backward_bucket(mi_unet* u, const float* params, const float* x, const float* dlogits, float* grads,
                             void* workspace, int training, uint64_t seed, int bucket, void* stream, void* ready_stream);
 
+/* ---- gradient exchange for hosts without torch.distributed ---------------------------------------------------------
+ * No counterpart in the reference, which trains on one device (reference/train.py:75); this is the exchange step of the
+ * data-parallel loop built on mi_unet_backward_bucket: one communicator per process and GPU, created with the device
+ * current, RCCL underneath (resolved at run time; a process that already holds a copy of RCCL uses that one).  The
+ * Python host reaches RCCL through torch.distributed instead (unet_amd/parallel.py) and does not call these.
+ *   rank 0: mi_comm_unique_id(id) ; the host hands the 128 bytes to every rank (its own launcher / rendezvous)
+ *   all   : mi_comm_init(nranks, rank, id, &c)                        collective: every rank must call it
+ *   step  : for each bucket b, after mi_unet_backward_bucket(..., b, stream, comm_stream):
+ *             mi_unet_bucket_range(u, b, &off, &cnt); mi_comm_allreduce_bucket(c, grads, off, cnt, comm_stream)
+ *           then `stream` waits for `comm_stream`, and AdamW runs with grad_scale = 1 / nranks
+ *   end   : mi_comm_destroy(c)
+ * -3: RCCL is not available in this process (mi_last_error says what was tried). */
+typedef struct mi_comm mi_comm;
+int mi_comm_unique_id(void* id128);                                                  /* 128 bytes out */
+int mi_comm_init(int nranks, int rank, const void* id128, mi_comm** out);
+/* in-place sum over the ranks of grads[offset : offset + count] (fp32), enqueued on `stream`; count 0: nothing */
+int mi_comm_allreduce_bucket(mi_comm* c, float* grads, int64_t offset, int64_t count, void* stream);
+int mi_comm_destroy(mi_comm* c);
+
 /* One optimisation step in one call: the body of the reference's inner loop, reference/train.py:111-118
  * (labels==2 -> 1 folded into the loss read, model(inputs), loss_function(outputs, labels), loss.backward(),
  * optimizer.step()), enqueued on `stream` from C: forward in training mode, Dice(+CE) loss forward and backward, the

@@ -85,6 +85,10 @@ PROTOTYPES = {
     "mi_unet_workspace_bytes": (C.c_size_t, [_P]),
     "mi_unet_num_buckets": (C.c_int, [_P]),
     "mi_unet_bucket_range": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "mi_comm_unique_id": (C.c_int, [_P]),
+    "mi_comm_init": (C.c_int, [C.c_int, C.c_int, _P, C.POINTER(_P)]),
+    "mi_comm_allreduce_bucket": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P]),
+    "mi_comm_destroy": (C.c_int, [_P]),
     "mi_unet_flops": (C.c_double, [_P, C.c_int]),
     "mi_unet_num_steps": (C.c_int, [_P, C.c_int]),
     "mi_unet_forward": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_uint64, _P]),

@@ -17,7 +17,7 @@ CSRC = HERE / "csrc"
 LIBDIR = HERE / "lib"
 OBJDIR = HERE / "lib" / "obj"
 LIBNAME = "libunet_mi355.so"
-SOURCES = ["igemm.hip", "igemm_dma.hip", "conv2d.hip", "wgrad2.hip", "wgrad3.hip", "norm.hip", "small.hip", "loss.hip", "pipeline.hip", "ops.hip", "engine.hip"]
+SOURCES = ["igemm.hip", "igemm_dma.hip", "conv2d.hip", "wgrad2.hip", "wgrad3.hip", "norm.hip", "small.hip", "loss.hip", "pipeline.hip", "ops.hip", "engine.hip", "comm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-munsafe-fp-atomics"]
 
 
