@@ -24,7 +24,8 @@ __global__ __launch_bounds__(256) void c1_s2_fwd_kernel(const C1Params p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];  // weights [KK][N], then partials [2][ppb][N]
     const int N = p.N;
     const int G = N / 8;
-    const int ppb = 256 / G;
+    const int nthr = blockDim.x;                // 256, or fewer when a row of the coarse grid has fewer than 256 / G columns
+    const int ppb = nthr / G;
     float* wl = sm;
     float* sst = sm + N * KK;
     const int grp = threadIdx.x % G, pl = threadIdx.x / G;
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(256) void c1_s2_fwd_kernel(const C1Params p) {
     // 2-D: the first row group's inputs are requested before the weights are staged, so the two round trips overlap
     float xr0[2 * ROWS + 1][3];
     if (KZ == 1) load_rows(blockIdx.y * C1F_YG * ROWS, 0, xr0);
-    for (int i = threadIdx.x; i < N * KK; i += 256) {
+    for (int i = threadIdx.x; i < N * KK; i += nthr) {
         const int n = i / KK, k = i - n * KK;
         wl[k * N + n] = (n < p.n_w1) ? p.w[n * KK + k] : p.w2[(n - p.n_w1) * KK + k];
     }
@@ -142,11 +143,11 @@ __global__ __launch_bounds__(256) void c1_s2_fwd_kernel(const C1Params p) {
                 }
             }
             __syncthreads();
-            for (int i = threadIdx.x; i < p.nstat * 2; i += 256) {
+            const int nrow = nthr >> 4;
+            for (int i = threadIdx.x; i < p.nstat * 2; i += nthr) {
                 const int ch = i >> 1, k = i & 1;
                 float a = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) a += sst[(k * 16 + r) * N + ch];
+                for (int r = 0; r < nrow; ++r) a += sst[(k * 16 + r) * N + ch];
                 atomicAdd(&p.stats[(((size_t)img * MI_NSLOT + slot) * p.stats_c) * 2 + i], (double)a);
             }
         } else {
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256) void c1_s2_fwd_kernel(const C1Params p) {
                 }
             }
             __syncthreads();
-            for (int i = threadIdx.x; i < p.nstat * 2; i += 256) {
+            for (int i = threadIdx.x; i < p.nstat * 2; i += nthr) {
                 const int ch = i >> 1, k = i & 1;
                 float a = 0.f;
                 for (int r = 0; r < ppb; ++r) a += sst[(k * ppb + r) * N + ch];
@@ -984,8 +985,13 @@ int small_lds(K kern, size_t bytes) {
 template <class TR, int KZ>
 int run_c1_fwd(const C1Params& p, hipStream_t st) {
     constexpr int KK = KZ * 9, ROWS = 4;
-    const int ppb = 256 / (p.N / 8);
-    const size_t lds = (size_t)(p.N * KK + 2 * ppb * p.N) * sizeof(float);
+    // threads: N / 8 lanes per coarse column, 256 at most; a grid row with fewer columns than that (48^3 coarse grids
+    // of 96^3 patches: 48 columns x 4 lanes) gets a smaller workgroup instead of a quarter of its lanes idling
+    const int G = p.N / 8;
+    int nthr = 256;
+    if (p.cd[2] * G < 256 && (16 * G) % 64 == 0) { nthr = (p.cd[2] + 15) / 16 * 16 * G; if (nthr > 256) nthr = 256; }
+    const int ppb = nthr / G;
+    const size_t lds = (size_t)(p.N * KK + 2 * (ppb > 16 ? ppb : 16) * p.N) * sizeof(float);
     if (KZ == 1 && (p.N == 32 || p.N == 64) && (size_t)p.fd[1] * p.fd[2] < (1u << 30) && p.fd[2] >= 2 * p.cd[2] && p.fd[1] >= 1) {
         static const bool strip = getenv("MI_NO_C1_STRIP") == nullptr;
         if (strip) {
@@ -999,7 +1005,7 @@ int run_c1_fwd(const C1Params& p, hipStream_t st) {
     }
     if (int rc = small_lds(c1_s2_fwd_kernel<TR, KZ>, lds)) return rc;
     dim3 grid((p.cd[2] + ppb - 1) / ppb, (p.cd[1] + ROWS * C1F_YG - 1) / (ROWS * C1F_YG), p.nb * p.cd[0]);
-    hipLaunchKernelGGL((c1_s2_fwd_kernel<TR, KZ>), grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL((c1_s2_fwd_kernel<TR, KZ>), grid, dim3(nthr), lds, st, p);
     return check_launch("c1_s2_fwd");
 }
 
