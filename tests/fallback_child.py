@@ -1,4 +1,4 @@
-"""Child process of tests/test_fallbacks_gpu.py: one bf16 forward + loss + backward of a small U-Net under whatever
+"""Child process of tests/test_fallbacks_gpu.py: one bf16 forward + loss + backward of a small U-Net (2-D, or 3-D with CHILD_3D=1) under whatever
 kernel-family switches the environment holds (they are read once per process), results saved with torch.save."""
 import os
 import sys
@@ -18,8 +18,13 @@ def main(out_path: str) -> None:
     m.to(dev).train()
     m.seed_dropout(7)
     g = torch.Generator().manual_seed(1)
-    x = torch.rand(2, 1, 96, 160, generator=g).to(dev)
-    t = (torch.rand(2, 1, 96, 160, generator=g) > 0.7).float().to(dev)
+    shape = (2, 1, 96, 160)
+    if os.environ.get("CHILD_3D"):       # the 3-D kernel families: a 16-128 network on two 32 x 48 x 64 volumes
+        m = unet_amd.UNet(3, 1, 1, channels, (2, 2, 2), num_res_units=2, dropout=0.1, compute_dtype=dt).to(dev).train()
+        m.seed_dropout(7)
+        shape = (2, 1, 32, 48, 64)
+    x = torch.rand(*shape, generator=g).to(dev)
+    t = (torch.rand(*shape, generator=g) > 0.7).float().to(dev)
     y = m(x)
     loss = unet_amd.DiceCELoss(sigmoid=True)(y, t)
     loss.backward()

@@ -17,16 +17,22 @@ from helpers import rel_l2
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
-SWITCHES = ["MI_NO_IGEMM_DMA", "MI_NO_IGEMM_DMA_S2", "MI_NO_CONV_DMA", "MI_NO_CONV_PHASE", "MI_NO_CONV_S2", "MI_NO_CONV_S2_STREAM", "MI_NO_CONV_K16", "MI_NO_CONV3D_K16", "MI_NO_WGRAD_DMA", "MI_NO_WGRAD_THICK",
-            "MI_NO_WGRAD_THICK_S2", "MI_NO_WGRAD_THIN", "MI_NO_C1_STRIP", "MI_NO_STENCIL3D_TILE", "MI_NO_SIDE_STREAM", "MI_NO_NORM_ON_LOAD", "MI_NO_FINISH_NORM", "MI_NO_FLAG_FORK",
+SWITCHES = ["MI_NO_IGEMM_DMA", "MI_NO_IGEMM_DMA_S2", "MI_NO_CONV_DMA", "MI_NO_CONV_PHASE", "MI_NO_CONV_S2", "MI_NO_CONV_S2_STREAM", "MI_NO_CONV_K16", "MI_NO_WGRAD_DMA", "MI_NO_WGRAD_THICK",
+            "MI_NO_WGRAD_THICK_S2", "MI_NO_WGRAD_THIN", "MI_NO_C1_STRIP", "MI_NO_SIDE_STREAM", "MI_NO_NORM_ON_LOAD", "MI_NO_FINISH_NORM", "MI_NO_FLAG_FORK",
             "MI_NO_CONV_FLAG", "MI_NO_LATE_REDUCE"]
 
 
-def run_child(tmp_path, switch):
-    out = str(tmp_path / ((switch or "default") + ".pt"))
-    env = {k: v for k, v in os.environ.items() if not k.startswith("MI_NO_")}
+# the families that only 3-D layers reach, run on a small 3-D network
+SWITCHES_3D = ["MI_NO_C1_MFMA3D", "MI_NO_CONV3D_K16", "MI_NO_IGEMM_DMA", "MI_NO_IGEMM_DMA_S2", "MI_NO_STENCIL3D_TILE", "MI_NO_FINISH_NORM"]
+
+
+def run_child(tmp_path, switch, three_d=False):
+    out = str(tmp_path / ((switch or "default") + ("_3d" if three_d else "") + ".pt"))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("MI_NO_") and k != "CHILD_3D"}
     if switch:
         env[switch] = "1"
+    if three_d:
+        env["CHILD_3D"] = "1"
     r = subprocess.run([sys.executable, os.path.join(HERE, "fallback_child.py"), out], env=env, capture_output=True, text=True, timeout=110)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     return torch.load(out, weights_only=True)
@@ -52,7 +58,24 @@ def test_older_kernels_agree_with_the_default_selection(tmp_path, baseline, swit
         assert ok, (k, rel_l2(d, g), float((d - g).abs().max()), scale)
 
 
-KERNEL_SWITCHES = [s for s in SWITCHES if s not in ("MI_NO_SIDE_STREAM", "MI_NO_NORM_ON_LOAD", "MI_NO_FINISH_NORM", "MI_NO_FLAG_FORK")]
+@pytest.fixture(scope="module")
+def baseline_3d(tmp_path_factory, dev):
+    return run_child(tmp_path_factory.mktemp("fallbacks3d"), None, three_d=True)
+
+
+@pytest.mark.parametrize("switch", SWITCHES_3D)
+def test_older_3d_kernels_agree_with_the_default_selection(tmp_path, baseline_3d, switch):
+    got = run_child(tmp_path, switch, three_d=True)
+    assert rel_l2(got["logits"], baseline_3d["logits"]) < 2e-2
+    assert abs(got["loss"] - baseline_3d["loss"]) < 2e-3 * abs(baseline_3d["loss"])
+    scale = max(float(g.abs().max()) for g in baseline_3d["grads"].values())
+    for k, g in baseline_3d["grads"].items():
+        d = got["grads"][k]
+        ok = rel_l2(d, g) < 0.15 or float((d - g).abs().max()) < 5e-3 * scale
+        assert ok, (k, rel_l2(d, g), float((d - g).abs().max()), scale)
+
+
+KERNEL_SWITCHES = [s for s in SWITCHES + ["MI_NO_C1_MFMA3D", "MI_NO_CONV3D_K16", "MI_NO_STENCIL3D_TILE"] if s not in ("MI_NO_SIDE_STREAM", "MI_NO_NORM_ON_LOAD", "MI_NO_FINISH_NORM", "MI_NO_FLAG_FORK")]
 
 
 def test_older_kernels_meet_the_operator_bounds_against_the_oracle(dev):

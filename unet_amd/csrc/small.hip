@@ -169,6 +169,164 @@ __global__ __launch_bounds__(256) void c1_s2_fwd_kernel(const C1Params p) {
     }
 }
 
+// ---- the same in 3-D on the matrix cores (bf16 storage, N = 16 or 32) -------------------------------------------------
+// 27 taps x N channels per output pixel are 864 FMAs per thread in the kernel above, which is bound by issuing them.
+// Here the 27 taps are the contraction of one MFMA step (padded to 32): a wave takes 16 consecutive coarse columns of
+// one row, gathers each lane's eight taps from an LDS tile of the input (3 planes x 17 rows of the workgroup's
+// 8 coarse rows) and multiplies by the weight fragments it keeps in registers.  The input and the weights stay fp32
+// in effect: each is split into a bf16 head and a bf16 remainder (x = hi + lo to 16 mantissa bits) and the three
+// products hi*hi, hi*lo, lo*hi are accumulated in fp32, so the result differs from the fp32 FMA chain by ~2^-16
+// relative, far below the bf16 rounding of the stored output.
+constexpr int C1M_TY = 8;
+__device__ __forceinline__ void split_bf16(float v, unsigned& hi, unsigned& lo) {
+    const unsigned short h = f32_to_bf16(v);
+    hi = h;
+    lo = f32_to_bf16(v - bf16_to_f32(h));
+}
+template <int NB, int TX16>      // 16-channel blocks (N = 16 * NB); 16-column blocks of a workgroup's tile
+__global__ __launch_bounds__(256) void c1_s2_fwd3d_mfma_kernel(const C1Params p) {
+    constexpr int tx16 = TX16;
+    constexpr int N = 16 * NB, FY = 2 * C1M_TY + 1;
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // input tile [3][FY][FX], then statistics [4 waves][N][2]
+    constexpr int FX = 32 * TX16 + 1;
+    float* sst = sm + 3 * FY * FX;
+    unsigned* tile = reinterpret_cast<unsigned*>(sm);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, g = lane >> 4;
+    const int cz = blockIdx.z % p.cd[0], img = blockIdx.z / p.cd[0];
+    const int cy0 = blockIdx.y * C1M_TY, cx0 = blockIdx.x * 16 * tx16;
+    const size_t fpix = (size_t)p.fd[0] * p.fd[1] * p.fd[2];
+    const size_t cpix = (size_t)p.cd[0] * p.cd[1] * p.cd[2];
+    const float* xin = p.x1 + (size_t)img * fpix;
+    // stage the input tile (zero outside the image): one (plane, row) per wave and step, consecutive lanes along x; all
+    // loads of a thread are requested before the first LDS store (a rolled loop waits for every load in turn: 14
+    // dependent round trips, two thirds of this kernel's time when it was written that way)
+    {
+        const int fz0 = 2 * cz - 1, fy0 = 2 * cy0 - 1, fx0 = 2 * cx0 - 1;
+        constexpr int NR = (3 * FY + 3) / 4, NX = (FX + 63) / 64;       // rows per wave, 64-lane steps along x
+        float tv[NR][NX];
+#pragma unroll
+        for (int ri = 0; ri < NR; ++ri) {
+            const int row = wave + 4 * ri;
+            const int z = row / FY, y = row - z * FY;
+            const int fz = fz0 + z, fy = fy0 + y;
+            const bool rok = row < 3 * FY && (unsigned)fz < (unsigned)p.fd[0] && (unsigned)fy < (unsigned)p.fd[1];
+            const float* src = xin + ((size_t)(rok ? fz : 0) * p.fd[1] + (rok ? fy : 0)) * p.fd[2];
+#pragma unroll
+            for (int xi = 0; xi < NX; ++xi) {
+                const int x = lane + 64 * xi, fx = fx0 + x;
+                tv[ri][xi] = (rok && x < FX && (unsigned)fx < (unsigned)p.fd[2]) ? src[fx] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int ri = 0; ri < NR; ++ri) {
+            const int row = wave + 4 * ri;
+#pragma unroll
+            for (int xi = 0; xi < NX; ++xi) {
+                const int x = lane + 64 * xi;
+                if (row < 3 * FY && x < FX) {       // split once per input value: bf16 head in the low half, remainder in the high half
+                    unsigned h, l;
+                    split_bf16(tv[ri][xi], h, l);
+                    tile[row * FX + x] = h | (l << 16);
+                }
+            }
+        }
+    }
+    // weight fragments (row = channel lr of block nb, contraction slots 8 g .. 8 g + 7 = taps, 27 .. 31 zero) and the
+    // tile offsets of the lane's eight taps
+    uint4 ahi[NB], alo[NB];
+    int toff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 8 * g + j;
+        const int kz = k / 9, r = k - kz * 9, ky = r / 3, kx = r - ky * 3;
+        toff[j] = k < 27 ? (kz * FY + ky) * FX + kx : 0;
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int n = nb * 16 + lr;
+        unsigned h[8], l[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 8 * g + j;
+            const float w = k < 27 ? ((n < p.n_w1) ? p.w[n * 27 + k] : p.w2[(n - p.n_w1) * 27 + k]) : 0.f;
+            split_bf16(w, h[j], l[j]);
+        }
+        ahi[nb] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+        alo[nb] = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+    }
+    float bv[NB][4], s1[NB][4], s2[NB][4];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ch = nb * 16 + 4 * g + j;
+            bv[nb][j] = (p.bias && ch >= p.bias_c0) ? p.bias[ch - p.bias_c0] : 0.f;
+            s1[nb][j] = 0.f; s2[nb][j] = 0.f;
+        }
+    __syncthreads();
+    const int nunit = C1M_TY * tx16;
+    for (int u = wave; u < nunit; u += 4) {
+        const int ry = u / tx16, xb = u - ry * tx16;
+        const int cy = cy0 + ry, cx = cx0 + 16 * xb + lr;
+        if (cy >= p.cd[1] || cx0 + 16 * xb >= p.cd[2]) continue;      // uniform over the wave
+        const int base = (2 * ry) * FX + 2 * (16 * xb + lr);
+        unsigned t8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t8[j] = tile[base + toff[j]];
+        // heads of two taps into one register, remainders into another
+        uint4 bhi, blo;
+        bhi.x = __builtin_amdgcn_perm(t8[1], t8[0], 0x05040100u); blo.x = __builtin_amdgcn_perm(t8[1], t8[0], 0x07060302u);
+        bhi.y = __builtin_amdgcn_perm(t8[3], t8[2], 0x05040100u); blo.y = __builtin_amdgcn_perm(t8[3], t8[2], 0x07060302u);
+        bhi.z = __builtin_amdgcn_perm(t8[5], t8[4], 0x05040100u); blo.z = __builtin_amdgcn_perm(t8[5], t8[4], 0x07060302u);
+        bhi.w = __builtin_amdgcn_perm(t8[7], t8[6], 0x05040100u); blo.w = __builtin_amdgcn_perm(t8[7], t8[6], 0x07060302u);
+        const bool valid = cx < p.cd[2];
+        const size_t gp = (size_t)img * cpix + ((size_t)cz * p.cd[1] + cy) * p.cd[2] + cx;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            v4f acc = v4f{0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, alo[nb]), __builtin_bit_cast(v8bf, bhi), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, ahi[nb]), __builtin_bit_cast(v8bf, blo), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, ahi[nb]), __builtin_bit_cast(v8bf, bhi), acc, 0, 0, 0);
+            if (valid) {
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o[j] = acc[j] + bv[nb][j];
+                    s1[nb][j] += acc[j];
+                    s2[nb][j] += acc[j] * acc[j];
+                }
+                const int ch = nb * 16 + 4 * g;
+                char* dst = (p.y2_out && ch >= p.n_o1) ? p.y2_out + (gp * p.y2o_pitch + p.y2o_coff + ch - p.n_o1) * 2
+                                                        : p.y_out + (gp * p.y_pitch + p.y_coff + ch) * 2;
+                store_n<BF16, 4>(dst, o);
+            }
+        }
+    }
+    if (p.stats) {
+        // fixed-order reduction: the 16 pixel lanes of a row by butterfly, the four waves through LDS, then fp64 accumulators
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float a = s1[nb][j], b = s2[nb][j];
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+                if (lr == 0) {
+                    const int ch = nb * 16 + 4 * g + j;
+                    sst[(wave * N + ch) * 2] = a;
+                    sst[(wave * N + ch) * 2 + 1] = b;
+                }
+            }
+        __syncthreads();
+        const int slot = (blockIdx.x + blockIdx.y) % MI_NSLOT;
+        for (int i = tid; i < p.nstat * 2 && i < N * 2; i += 256) {
+            const float v = ((sst[i] + sst[N * 2 + i]) + sst[2 * N * 2 + i]) + sst[3 * N * 2 + i];
+            atomicAdd(&p.stats[(((size_t)img * MI_NSLOT + slot) * p.stats_c) * 2 + i], (double)v);
+        }
+    }
+}
+
 // ---- the same for 2-D and N = 32 (the first encoder layer with its residual branch, the data gradient of the last
 // transposed convolution), as a strip walk.  Measured on the kernel above with its parts switched off: without the
 // stores, the FMAs and the statistics it still takes 34 of its 58 us - the per-workgroup set-up (weights to LDS, bias,
@@ -1001,6 +1159,19 @@ int run_c1_fwd(const C1Params& p, hipStream_t st) {
             if (p.N == 32) hipLaunchKernelGGL((c1_s2_fwd32_kernel<TR, R2, G2, 32>), grid, dim3(256), 0, st, p);
             else hipLaunchKernelGGL((c1_s2_fwd32_kernel<TR, R2, G2, 64>), grid, dim3(256), 0, st, p);
             return check_launch("c1_s2_fwd32");
+        }
+    }
+    if (KZ == 3 && TR::ESZ == 2 && (p.N == 16 || p.N == 32) && (long long)p.fd[1] * p.fd[2] < (1ll << 30)) {
+        static const bool mfma = getenv("MI_NO_C1_MFMA3D") == nullptr;
+        if (mfma) {
+            int tx16 = (p.cd[2] + 15) / 16;
+            if (tx16 > 4) tx16 = 4;
+            const size_t l2 = (size_t)(3 * (2 * C1M_TY + 1) * (32 * tx16 + 1) + 4 * p.N * 2) * sizeof(float);
+            dim3 g2((p.cd[2] + 16 * tx16 - 1) / (16 * tx16), (p.cd[1] + C1M_TY - 1) / C1M_TY, p.nb * p.cd[0]);
+#define C1M_CASE(NBV, TXV) if (p.N == 16 * NBV && tx16 == TXV) hipLaunchKernelGGL((c1_s2_fwd3d_mfma_kernel<NBV, TXV>), g2, dim3(256), l2, st, p);
+            C1M_CASE(1, 1) C1M_CASE(1, 2) C1M_CASE(1, 3) C1M_CASE(1, 4) C1M_CASE(2, 1) C1M_CASE(2, 2) C1M_CASE(2, 3) C1M_CASE(2, 4)
+#undef C1M_CASE
+            return check_launch("c1_s2_fwd3d_mfma");
         }
     }
     if (int rc = small_lds(c1_s2_fwd_kernel<TR, KZ>, lds)) return rc;
