@@ -894,13 +894,25 @@ __global__ __launch_bounds__(256) void stencil3d_tile_kernel(const StencilParams
     const int img = blockIdx.z;
     const size_t npix = (size_t)p.d[0] * p.d[1] * p.d[2];
     const float* in = p.in + (size_t)img * npix;
-    for (int i = threadIdx.x; i < PZ * PY * PQ; i += 256) {
-        const int q = i % PQ, py = (i / PQ) % PY, pz = i / (PQ * PY);
-        const int z = z0 - 1 + pz, y = y0 - 1 + py, x = x0 - 4 + 4 * q;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((unsigned)z < (unsigned)p.d[0] && (unsigned)y < (unsigned)p.d[1] && (unsigned)x < (unsigned)p.d[2])
-            v = *reinterpret_cast<const float4*>(in + ((size_t)z * p.d[1] + y) * p.d[2] + x);
-        *reinterpret_cast<float4*>(&tile[pz][py][4 * q]) = v;
+    {
+        // all of a thread's tile loads are requested before its first LDS store (one round trip instead of three)
+        constexpr int NIT = (PZ * PY * PQ + 255) / 256;
+        float4 tv[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = threadIdx.x + 256 * it;
+            const int q = i % PQ, py = (i / PQ) % PY, pz = i / (PQ * PY);
+            const int z = z0 - 1 + pz, y = y0 - 1 + py, x = x0 - 4 + 4 * q;
+            tv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < PZ * PY * PQ && (unsigned)z < (unsigned)p.d[0] && (unsigned)y < (unsigned)p.d[1] && (unsigned)x < (unsigned)p.d[2])
+                tv[it] = *reinterpret_cast<const float4*>(in + ((size_t)z * p.d[1] + y) * p.d[2] + x);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = threadIdx.x + 256 * it;
+            const int q = i % PQ, py = (i / PQ) % PY, pz = i / (PQ * PY);
+            if (i < PZ * PY * PQ) *reinterpret_cast<float4*>(&tile[pz][py][4 * q]) = tv[it];
+        }
     }
     float w[27];
 #pragma unroll
