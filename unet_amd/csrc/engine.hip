@@ -846,7 +846,7 @@ bool build(mi_unet& u) {
                 p.nsplit = c1_wgrad_slabs(p.N, p.cd);
                 po = B.alloc((size_t)p.nsplit * KK * K * sizeof(float)); pb = B.alloc((size_t)p.nsplit * K * sizeof(float));
                 REL(s, p, partial, B_ARENA, po); REL(s, p, partial_bias, B_ARENA, pb);
-                s.kernel = dt ? "c1_s2_wgrad_kernel<BF16>" : "c1_s2_wgrad_kernel<F32>";
+                s.kernel = c1_wgrad3d_mfma_applicable(dt, p) ? "c1_s2_wgrad3d_mfma_kernel" : dt ? "c1_s2_wgrad_kernel<BF16>" : "c1_s2_wgrad_kernel<F32>";
                 s.work = (double)nb * (u.rp[0] * 4.0 + u.rp[1] * (double)K * esz);
                 u.flops_bwd += 2.0 * nb * u.rp[1] * KK * (double)K;
                 B.add_reduce(po, pb, p.nsplit, KK, K, 1, 0, K, KK, nat, P + ".0.conv.weight", "");
@@ -998,7 +998,7 @@ bool build(mi_unet& u) {
                     p.nsplit = c1_wgrad_slabs(p.N, p.cd);
                     po = B.alloc((size_t)p.nsplit * KK * 2 * cout * sizeof(float)); pb = B.alloc((size_t)p.nsplit * 2 * cout * sizeof(float));
                     REL(s, p, partial, B_ARENA, po); REL(s, p, partial_bias, B_ARENA, pb);
-                    s.kernel = dt ? "c1_s2_wgrad_kernel<BF16>" : "c1_s2_wgrad_kernel<F32>";
+                    s.kernel = c1_wgrad3d_mfma_applicable(dt, p) ? "c1_s2_wgrad3d_mfma_kernel" : dt ? "c1_s2_wgrad_kernel<BF16>" : "c1_s2_wgrad_kernel<F32>";
                     s.work = (double)nb * (u.rp[0] * 4.0 + u.rp[1] * 2.0 * cout * esz);
                     u.flops_bwd += 2.0 * nb * u.rp[1] * KK * 2.0 * cout;
                     B.add_reduce(po, pb, p.nsplit, KK, 2 * cout, 1, 0, cout, KK, nat, D.un[0].wname, D.un[0].bname);

@@ -198,6 +198,7 @@ int norm_bwd_reduce_blocks(int npix, int c);   // workgroups per image of the ba
 int launch_c1_s2_fwd(int dtype, const C1Params& p, hipStream_t st);
 int launch_c1_s2_T(int dtype, const C1Params& p, hipStream_t st);
 int launch_c1_s2_wgrad(int dtype, const C1Params& p, hipStream_t st);
+bool c1_wgrad3d_mfma_applicable(int dtype, const C1Params& p);
 int launch_stencil(const StencilParams& p, hipStream_t st);
 bool stencil_norm_on_load_ok(const StencilParams& p);   // small.hip: the 2-D strip kernel serves p (it can normalise on load)
 int launch_stencil_wgrad(const StencilParams& p, hipStream_t st);

@@ -836,6 +836,159 @@ __global__ __launch_bounds__(256) void c1_s2_wgrad_kernel(const C1Params p) {
         }
 }
 
+// ---- the same weight gradient in 3-D on the matrix cores (bf16 storage, N = 16 or 32) ---------------------------------
+// partial[slab][k][n] = sum_p Y[p][n] * x[p -> tap k] is a matrix product with the pixels as contraction: a wave takes
+// 32 consecutive coarse pixels of a row per MFMA step, rows = channels (Y loaded as 16-byte vectors and transposed
+// through LDS: two-byte loads of single channels cost a third of the kernel), columns = the 27 taps of all three kz
+// planes, a column of ones (the bias gradient) and four empty ones.  A workgroup's tile is four coarse rows of up to 64
+// pixels, one row per wave; its image values (3 planes x 9 rows) are staged in LDS once and gathered per tap from there.  The image values are split into a bf16 head and
+// remainder (two products, fp32 accuracy as in c1_s2_fwd3d_mfma_kernel); Y is bf16 as stored.  The vector-ALU kernel
+// above runs once per kz plane, reads Y three times and spends 864 FMAs per pixel and channel group.
+template <int NB, int TX32>       // 16-channel blocks (N = 16 NB); 32-pixel units along x in a workgroup's tile (1 or 2)
+__global__ __launch_bounds__(256) void c1_s2_wgrad3d_mfma_kernel(const C1Params p) {
+    constexpr int N = 16 * NB, TY = 4, FY = 2 * TY + 1, FX = 64 * TX32 + 1;
+    constexpr int PXP = 32 * TX32 + 8;               // pixels per channel row of the transposed Y (144 or 80 bytes: 16-byte aligned)
+    constexpr int TILE_B = 3 * FY * FX * 4, YSH_B = 4 * N * PXP * 2, RED_B = 4 * 32 * (N + 1) * 4;
+    __shared__ __align__(16) unsigned char smem[(TILE_B + 15) / 16 * 16 + YSH_B > RED_B ? (TILE_B + 15) / 16 * 16 + YSH_B : RED_B];
+    unsigned* tile = reinterpret_cast<unsigned*>(smem);                       // image values of a tile: bf16 head | remainder << 16
+    unsigned short* ysh = reinterpret_cast<unsigned short*>(smem + (TILE_B + 15) / 16 * 16);   // [wave][channel][pixel]
+    float (*red)[32][N + 1] = reinterpret_cast<float (*)[32][N + 1]>(smem);   // after the last tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, g = lane >> 4;
+    const size_t fpix = (size_t)p.fd[0] * p.fd[1] * p.fd[2];
+    const int ntx = (p.cd[2] + 32 * TX32 - 1) / (32 * TX32), nty = (p.cd[1] + TY - 1) / TY;
+    const long long ntile = (long long)p.nb * p.cd[0] * nty * ntx;
+    // the lane's tap per column block: tile offset of (kz, ky, kx), or the ones column (27), or nothing (28 .. 31)
+    int toff[2], tkind[2];
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) {
+        const int k = tb * 16 + lr;
+        tkind[tb] = k < 27 ? 0 : k == 27 ? 1 : 2;
+        const int kz = k / 9, r = k - kz * 9, ky = r / 3, kx = r - ky * 3;
+        toff[tb] = k < 27 ? (kz * FY + ky) * FX + kx : 0;
+    }
+    v4f acc[NB][2];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) acc[nb][tb] = v4f{0.f, 0.f, 0.f, 0.f};
+
+    // A tile's global loads are requested one tile ahead (registers), so that their latency runs beside the previous
+    // tile's LDS gathers and MFMAs; every load of a thread is in flight before its first LDS store.
+    constexpr int NR = (3 * FY + 3) / 4, NX = (FX + 63) / 64, NV = 32 * TX32 * N / 8 / 64;
+    float tv[NR][NX];
+    uint4 yraw[NV];
+    auto request = [&](long long t) {
+        const int txi = (int)(t % ntx); long long r1 = t / ntx;
+        const int tyi = (int)(r1 % nty); r1 /= nty;
+        const int cz = (int)(r1 % p.cd[0]), img = (int)(r1 / p.cd[0]);
+        const int cy0 = tyi * TY, cxt = txi * 32 * TX32;
+        const float* xin = p.x1 + (size_t)img * fpix;
+        const int fz0 = 2 * cz - 1, fy0 = 2 * cy0 - 1, fx0 = 2 * cxt - 1;
+#pragma unroll
+        for (int ri = 0; ri < NR; ++ri) {
+            const int row = wave + 4 * ri;
+            const int z = row / FY, y = row - z * FY;
+            const int fz = fz0 + z, fy = fy0 + y;
+            const bool rok = row < 3 * FY && (unsigned)fz < (unsigned)p.fd[0] && (unsigned)fy < (unsigned)p.fd[1];
+            const float* src = xin + ((size_t)(rok ? fz : 0) * p.fd[1] + (rok ? fy : 0)) * p.fd[2];
+#pragma unroll
+            for (int xi = 0; xi < NX; ++xi) {
+                const int x = lane + 64 * xi, fx = fx0 + x;
+                tv[ri][xi] = (rok && x < FX && (unsigned)fx < (unsigned)p.fd[2]) ? src[fx] : 0.f;   // zero outside the image
+            }
+        }
+        // Y of this wave's row as 16-byte vectors (eight channels of a pixel)
+        const int cy = cy0 + wave;
+        const bool rowok = cy < p.cd[1];
+        const size_t grow = ((size_t)img * p.cd[0] + cz) * p.cd[1] + cy;
+#pragma unroll
+        for (int r = 0; r < NV; ++r) {
+            const int v = lane + 64 * r, px = v / (N / 8), ch = (v % (N / 8)) * 8;
+            const bool second = ch >= p.n_y1;
+            const unsigned short* ysrc = reinterpret_cast<const unsigned short*>(second ? p.y2 : p.y);
+            const int ypitch = second ? p.y2_pitch : p.y_pitch;
+            const int ych = second ? p.y2_coff + ch - p.n_y1 : p.y_coff + ch;
+            yraw[r] = (rowok && cxt + px < p.cd[2]) ? *reinterpret_cast<const uint4*>(ysrc + (grow * p.cd[2] + cxt + px) * ypitch + ych)
+                                                    : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    if ((long long)blockIdx.x < ntile) request(blockIdx.x);
+    for (long long t = blockIdx.x; t < ntile; t += gridDim.x) {
+        __syncthreads();                                  // the previous tile has been consumed
+#pragma unroll
+        for (int ri = 0; ri < NR; ++ri) {
+            const int row = wave + 4 * ri;
+#pragma unroll
+            for (int xi = 0; xi < NX; ++xi) {
+                const int x = lane + 64 * xi;
+                if (row < 3 * FY && x < FX) {
+                    unsigned h, l;
+                    split_bf16(tv[ri][xi], h, l);
+                    tile[row * FX + x] = h | (l << 16);
+                }
+            }
+        }
+        // Y scattered into LDS as [channel][pixel]: the MFMA's row operand is eight pixels of one channel per lane
+#pragma unroll
+        for (int r = 0; r < NV; ++r) {
+            const int v = lane + 64 * r, px = v / (N / 8), ch = (v % (N / 8)) * 8;
+            unsigned short* dst = ysh + ((size_t)wave * N + ch) * PXP + px;
+            dst[0 * PXP] = (unsigned short)yraw[r].x; dst[1 * PXP] = (unsigned short)(yraw[r].x >> 16);
+            dst[2 * PXP] = (unsigned short)yraw[r].y; dst[3 * PXP] = (unsigned short)(yraw[r].y >> 16);
+            dst[4 * PXP] = (unsigned short)yraw[r].z; dst[5 * PXP] = (unsigned short)(yraw[r].z >> 16);
+            dst[6 * PXP] = (unsigned short)yraw[r].w; dst[7 * PXP] = (unsigned short)(yraw[r].w >> 16);
+        }
+        if (t + gridDim.x < ntile) request(t + gridDim.x);
+        __syncthreads();
+#pragma unroll
+        for (int xb = 0; xb < TX32; ++xb) {
+            uint4 afr[NB], bhi[2], blo[2];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                afr[nb] = *reinterpret_cast<const uint4*>(ysh + ((size_t)wave * N + nb * 16 + lr) * PXP + xb * 32 + 8 * g);
+            const int base = (2 * wave) * FX + 2 * (xb * 32 + 8 * g);
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) {
+                unsigned t8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    t8[j] = tile[base + toff[tb] + 2 * j];
+                    if (tkind[tb] == 1) t8[j] = 0x3f80u;          // the column of ones (Y is zero where the pixel is not)
+                    if (tkind[tb] == 2) t8[j] = 0u;
+                }
+                bhi[tb].x = __builtin_amdgcn_perm(t8[1], t8[0], 0x05040100u); blo[tb].x = __builtin_amdgcn_perm(t8[1], t8[0], 0x07060302u);
+                bhi[tb].y = __builtin_amdgcn_perm(t8[3], t8[2], 0x05040100u); blo[tb].y = __builtin_amdgcn_perm(t8[3], t8[2], 0x07060302u);
+                bhi[tb].z = __builtin_amdgcn_perm(t8[5], t8[4], 0x05040100u); blo[tb].z = __builtin_amdgcn_perm(t8[5], t8[4], 0x07060302u);
+                bhi[tb].w = __builtin_amdgcn_perm(t8[7], t8[6], 0x05040100u); blo[tb].w = __builtin_amdgcn_perm(t8[7], t8[6], 0x07060302u);
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb) {
+                    acc[nb][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, afr[nb]), __builtin_bit_cast(v8bf, blo[tb]), acc[nb][tb], 0, 0, 0);
+                    acc[nb][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, afr[nb]), __builtin_bit_cast(v8bf, bhi[tb]), acc[nb][tb], 0, 0, 0);
+                }
+        }
+    }
+    // accumulator (nb, tb)[j] of lane (lr, g) is channel nb * 16 + 4 g + j, tap tb * 16 + lr; the four waves meet in LDS
+    __syncthreads();                                      // red[] lies over the tile
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) red[wave][tb * 16 + lr][nb * 16 + 4 * g + j] = acc[nb][tb][j];
+    __syncthreads();
+    const size_t slab = blockIdx.x;
+    for (int i = tid; i < 28 * N; i += 256) {
+        const int k = i / N, n = i - k * N;
+        const float a = ((red[0][k][n] + red[1][k][n]) + red[2][k][n]) + red[3][k][n];
+        if (k < 27) p.partial[(slab * 27 + k) * p.N + n] = a;
+        else p.partial_bias[slab * p.N + n] = a;
+    }
+}
+
 // ---- one-channel 3^d stencil: out = sum_k w[k] * in[p + k - 1] + bias + addend ------------
 // Thread = four consecutive pixels of a row (one aligned 16-byte load per stencil row plus the two
 // neighbours); needs a row length that is a multiple of 4.
@@ -1237,11 +1390,26 @@ int c1_wgrad_slabs(int N, const int cd[3]) {
     return xblocks * rb;
 }
 
+// whether launch_c1_s2_wgrad() takes the matrix-core kernel for these operands
+bool c1_wgrad3d_mfma_applicable(int dtype, const C1Params& p) {
+    static const bool mfma = getenv("MI_NO_C1_MFMA3D") == nullptr;
+    return mfma && dtype && p.ndim == 3 && (p.N == 16 || p.N == 32) && p.n_y1 % 16 == 0 && p.y_pitch % 8 == 0 && p.y_coff % 8 == 0 &&
+           (p.n_y1 >= p.N || (p.y2_pitch % 8 == 0 && p.y2_coff % 8 == 0));
+}
+
 // partial: [nsplit][KK][N] floats, partial_bias: [nsplit][N] floats
 int launch_c1_s2_wgrad(int dtype, const C1Params& p, hipStream_t st) {
     MI_CHECK(p.N % 8 == 0 && p.N >= 8 && p.N <= 512 && p.N / C1_WGRAD_CG <= 256, "N must be a multiple of 8, at most 512");
     MI_CHECK(p.n_y1 % 8 == 0 && p.n_y1 > 0 && (p.n_y1 >= p.N || p.y2 != nullptr), "second source missing or misaligned");
     MI_CHECK(p.nsplit == c1_wgrad_slabs(p.N, p.cd), "nsplit must come from c1_wgrad_slabs()");
+    if (c1_wgrad3d_mfma_applicable(dtype, p)) {
+        const bool wide = p.cd[2] > 32;
+        if (p.N == 16) { if (wide) hipLaunchKernelGGL((c1_s2_wgrad3d_mfma_kernel<1, 2>), dim3(p.nsplit), dim3(256), 0, st, p);
+                         else hipLaunchKernelGGL((c1_s2_wgrad3d_mfma_kernel<1, 1>), dim3(p.nsplit), dim3(256), 0, st, p); }
+        else { if (wide) hipLaunchKernelGGL((c1_s2_wgrad3d_mfma_kernel<2, 2>), dim3(p.nsplit), dim3(256), 0, st, p);
+               else hipLaunchKernelGGL((c1_s2_wgrad3d_mfma_kernel<2, 1>), dim3(p.nsplit), dim3(256), 0, st, p); }
+        return check_launch("c1_s2_wgrad3d_mfma");
+    }
     const bool quad = p.N / C1_WGRAD_CG == 4;
     const size_t lds = (size_t)(quad ? 16 : 4) * p.N * 10 * sizeof(float);   // one image per wave, per 16-lane row in the quad variant
     dim3 grid(p.nsplit, p.ndim == 3 ? 3 : 1);
