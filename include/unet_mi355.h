@@ -276,6 +276,16 @@ size_t mi_conv_wgrad_workspace_bytes(const mi_conv_desc* d);
 int mi_conv_wgrad(const mi_conv_desc* d, const mi_tensor* x, const mi_tensor* dy, float* dw, float* db,
                   void* workspace, void* stream);
 
+/* Weight gradient of the 3^d stride-2 convolution between a ONE-channel fp32 tensor on the fine grid (x: [nb][fine_dims],
+ * dense) and an n-channel channels-last tensor on the coarse grid (y, fine_dims / 2; ptr2 / c1 name a second source for
+ * the channels from c1 on): dw[c][k] = sum_p y[p][c] * x[2p + k - 1], db[c] = sum_p y[p][c] (may be NULL).  This is the
+ * first encoder convolution (x = image, y = gradient of its output; torch layout [n][1][k..]) and equally the last
+ * transposed convolution (x = gradient of its one-channel output, y = its input; torch layout [n][1][k..] again).
+ * The network engine runs these two layers on kernels of their own; this entry point reaches the same kernels. */
+size_t mi_conv1_wgrad_workspace_bytes(int ndim, int n, const int32_t* fine_dims);
+int mi_conv1_wgrad(int dtype, int ndim, int nb, const int32_t* fine_dims, int n, const float* x, const mi_tensor* y,
+                   float* dw, float* db, void* workspace, void* stream);
+
 /* InstanceNorm(eps, no affine) -> Dropout(p) -> PReLU(alpha) (+ residual): MONAI ADN "NDA" */
 int mi_instnorm_prelu_fwd(int dtype, int nb, int64_t npix, int c, const mi_tensor* raw, const double* stats,
                           const float* alpha, const mi_tensor* res, const mi_tensor* out, float dropout,

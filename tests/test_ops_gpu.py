@@ -129,6 +129,61 @@ def test_conv_exact_integer_data(dev, mode):
     assert torch.equal(from_cl(y), y_ref)
 
 
+C1_CASES = [
+    # nd, fine spatial, channels of the first source, channels of the second source
+    (2, (32, 48), 16, 0),
+    (2, (36, 20), 32, 0),
+    (2, (24, 136), 16, 16),
+    (3, (8, 8, 8), 16, 0),
+    (3, (12, 20, 72), 16, 0),     # 10 coarse rows (ragged four-row tiles), 36 coarse pixels per row (ragged 64-pixel tile)
+    (3, (6, 36, 136), 16, 16),    # two sources; 68 coarse pixels: two tiles per row, the second nearly empty
+    (3, (10, 12, 40), 32, 0),     # 20 coarse pixels: the 32-pixel tile
+    (3, (4, 8, 24), 16, 32),      # 48 channels: the vector-ALU kernel in both modes
+]
+
+
+def _conv1_ref(x, dy, nd):
+    n = dy.shape[1]
+    w = torch.zeros([n, 1] + [3] * nd, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(n, dtype=torch.float64, requires_grad=True)
+    f = F.conv2d if nd == 2 else F.conv3d
+    f(x[:, None].double(), w, b, stride=2, padding=1).backward(dy.double())
+    return w.grad, b.grad
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", C1_CASES, ids=lambda c: "nd%d_%s_%d+%d" % (c[0], "x".join(map(str, c[1])), c[2], c[3]))
+def test_one_channel_stride2_wgrad(dev, mode, case):
+    """The weight gradient of the two layers with one channel on the fine side (first encoder convolution, last
+    transposed convolution) against torch's CPU convolution in fp64: 5e-5 of the largest element in fp32; in bf16 the
+    channel tensor is bf16 on both sides and the fp32 image is taken as a bf16 head plus remainder (2e-4).  Then with
+    small integers, where every product and sum is exact: bit for bit."""
+    nd, sp, c1, c2 = case
+    dt = DT[mode]
+    g = torch.Generator().manual_seed(99 + c1 + 3 * c2 + sp[-1])
+    nb = 2
+    csp = [v // 2 for v in sp]
+    for exact in (False, True):
+        if exact:
+            x = torch.randint(-4, 5, (nb, *sp), generator=g).float()
+            dy = torch.randint(-2, 3, (nb, c1 + c2, *csp), generator=g).float()
+        else:
+            x = torch.randn(nb, *sp, generator=g)
+            dy = torch.randn(nb, c1 + c2, *csp, generator=g)
+            if mode == "bf16":
+                dy = bf16_round(dy)
+        dw_ref, db_ref = _conv1_ref(x, dy, nd)
+        ya = to_cl(dy[:, :c1].contiguous(), dt, dev)
+        yb = to_cl(dy[:, c1:].contiguous(), dt, dev) if c2 else None
+        dw, db = ops.conv1_wgrad(x.to(dev), ya, yb)
+        torch.cuda.synchronize()
+        if exact:
+            assert torch.equal(dw.cpu().double(), dw_ref) and torch.equal(db.cpu().double(), db_ref)
+        else:
+            assert rel_err(dw.cpu().double(), dw_ref) < TOL_W[mode]
+            assert rel_err(db.cpu().double(), db_ref) < TOL_W[mode]
+
+
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 @pytest.mark.parametrize("nd,sp,c", [(2, (32, 32), 16), (2, (20, 12), 64), (3, (4, 6, 8), 32), (2, (16, 16), 256)])
 def test_instnorm_prelu_fwd_bwd(dev, mode, nd, sp, c):

@@ -131,6 +131,49 @@ int mi_conv_wgrad(const mi_conv_desc* d, const mi_tensor* x, const mi_tensor* dy
     return launch_reduce_one(rd, (hipStream_t)stream);
 }
 
+static int conv1_geometry(int ndim, int nb, const int32_t* fine_dims, int n, C1Params& p) {
+    MI_CHECK(ndim == 2 || ndim == 3, "ndim must be 2 or 3");
+    MI_CHECK(nb > 0 && fine_dims, "batch must be positive, dims must be given");
+    MI_CHECK(n % 8 == 0 && n >= 8 && n <= 512, "channels must be a multiple of 8, at most 512");
+    MI_CHECK(ndim == 3 || fine_dims[0] == 1, "fine_dims[0] must be 1 in 2-D");
+    memset(&p, 0, sizeof(p));
+    p.ndim = ndim; p.nb = nb; p.N = n;
+    for (int i = 0; i < 3; ++i) {
+        const bool flat = ndim == 2 && i == 0;
+        MI_CHECK(fine_dims[i] > 0 && (flat || fine_dims[i] % 2 == 0), "odd size under stride 2");
+        p.fd[i] = fine_dims[i]; p.cd[i] = flat ? 1 : fine_dims[i] / 2;
+    }
+    p.nsplit = c1_wgrad_slabs(n, p.cd);
+    return 0;
+}
+
+size_t mi_conv1_wgrad_workspace_bytes(int ndim, int n, const int32_t* fine_dims) {
+    C1Params p;
+    if (conv1_geometry(ndim, 1, fine_dims, n, p)) return 0;
+    return (size_t)p.nsplit * ((ndim == 3 ? 27 : 9) + 1) * n * sizeof(float) + 256;
+}
+
+int mi_conv1_wgrad(int dtype, int ndim, int nb, const int32_t* fine_dims, int n, const float* x, const mi_tensor* y, float* dw,
+                   float* db, void* workspace, void* stream) {
+    MI_CHECK(dtype == 0 || dtype == 1, "dtype must be 0 or 1");
+    MI_CHECK(x && y && y->ptr && dw && workspace, "null argument");
+    C1Params p;
+    if (int r = conv1_geometry(ndim, nb, fine_dims, n, p)) return r;
+    const int KK = ndim == 3 ? 27 : 9;
+    p.x1 = x;
+    p.y = (const char*)y->ptr; p.y_pitch = y->pitch; p.y_coff = y->coff; p.n_y1 = n;
+    if (y->ptr2) { p.y2 = (const char*)y->ptr2; p.y2_pitch = y->pitch2; p.y2_coff = y->coff2; p.n_y1 = y->c1; }
+    p.partial = (float*)workspace;
+    p.partial_bias = p.partial + (size_t)p.nsplit * KK * n;
+    if (int r = launch_c1_s2_wgrad(dtype, p, (hipStream_t)stream)) return r;
+    ReduceDesc rd; memset(&rd, 0, sizeof(rd));
+    rd.partial = p.partial; rd.partial_bias = p.partial_bias; rd.nslab = p.nsplit; rd.ntaps = KK;
+    rd.Ftot = n; rd.S = 1; rd.f_off = 0; rd.Fcnt = n; rd.KK = KK;
+    for (int i = 0; i < KK; ++i) rd.kidx[i] = (signed char)i;
+    rd.dst_w = dw; rd.dst_b = db;
+    return launch_reduce_one(rd, (hipStream_t)stream);
+}
+
 static void fill_drop(NormParams& p, float dropout, uint64_t seed, uint32_t layer) {
     p.seed = seed; p.layer = layer;
     norm_set_dropout(p, dropout);

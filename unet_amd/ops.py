@@ -98,6 +98,25 @@ def conv_wgrad(x, dy, w_shape, ksize=3, stride=1, transposed=False):
     return dw, db
 
 
+def conv1_wgrad(x, y, y2=None):
+    """Weight and bias gradient of the 3^d stride-2 convolution between a one-channel fp32 tensor ``x``
+    ([N, (D,) H, W], fine grid) and channels-last ``y`` (coarse grid; ``y2``: a second source whose channels follow
+    those of ``y``).  Returns (dw [C, 1, 3, ..] fp32, db [C] fp32)."""
+    lib = _lib.load()
+    nd = x.dim() - 1
+    n = y.shape[-1] + (y2.shape[-1] if y2 is not None else 0)
+    dims = (C.c_int32 * 3)(*([1] * (3 - nd) + [int(v) for v in x.shape[1:]]))
+    ws = torch.empty(lib.mi_conv1_wgrad_workspace_bytes(nd, n, dims), dtype=torch.uint8, device=x.device)
+    dw = torch.empty([n, 1] + [3] * nd, dtype=torch.float32, device=x.device)
+    db = torch.empty(n, dtype=torch.float32, device=x.device)
+    ty = _ten(y)
+    if y2 is not None:
+        ty.ptr2, ty.pitch2, ty.coff2, ty.c1 = y2.data_ptr(), y2.shape[-1], 0, y.shape[-1]
+    _lib.check(lib.mi_conv1_wgrad(_DT[y.dtype], nd, x.shape[0], dims, n, x.data_ptr(), C.byref(ty), dw.data_ptr(),
+                                  db.data_ptr(), ws.data_ptr(), _lib.current_stream(x.device)), "mi_conv1_wgrad")
+    return dw, db
+
+
 def instnorm_prelu_fwd(raw, stats, alpha, res=None, dropout=0.0, seed=0, layer=0):
     lib = _lib.load()
     nb, c = raw.shape[0], raw.shape[-1]
