@@ -282,6 +282,15 @@ int mi_conv_wgrad(const mi_conv_desc* d, const mi_tensor* x, const mi_tensor* dy
  * first encoder convolution (x = image, y = gradient of its output; torch layout [n][1][k..]) and equally the last
  * transposed convolution (x = gradient of its one-channel output, y = its input; torch layout [n][1][k..] again).
  * The network engine runs these two layers on kernels of their own; this entry point reaches the same kernels. */
+/* The same two layers forward.  mi_conv1_forward: y[p][c] = bias[c] + sum_k w[c][k] * x[2p + k - 1] (F.conv, k 3, stride 2,
+ * padding 1, one input channel; w [n][1][k..] fp32, bias may be NULL; y->ptr2 / c1 name a second destination for the
+ * channels from c1 on; stats as in mi_conv_forward, [nb][8][n][2]).  mi_conv1_transposed: x_out[2p + k - 1] += w[c][k] *
+ * y[p][c], plus bias[0] (F.conv_transpose, k 3, stride 2, padding 1, output_padding 1, one output channel; w [n][1][k..];
+ * stats [nb][8][1][2] of the bias-free result).  The data gradient of either layer is the other one's forward. */
+int mi_conv1_forward(int dtype, int ndim, int nb, const int32_t* fine_dims, int n, const float* x, const float* w,
+                     const float* bias, const mi_tensor* y, double* stats, void* stream);
+int mi_conv1_transposed(int dtype, int ndim, int nb, const int32_t* fine_dims, int n, const mi_tensor* y, const float* w,
+                        const float* bias, float* x_out, double* stats, void* stream);
 size_t mi_conv1_wgrad_workspace_bytes(int ndim, int n, const int32_t* fine_dims);
 int mi_conv1_wgrad(int dtype, int ndim, int nb, const int32_t* fine_dims, int n, const float* x, const mi_tensor* y,
                    float* dw, float* db, void* workspace, void* stream);

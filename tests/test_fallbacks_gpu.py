@@ -87,6 +87,6 @@ def test_older_kernels_meet_the_operator_bounds_against_the_oracle(dev):
     for s in KERNEL_SWITCHES:
         env[s] = "1"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(HERE, "test_ops_gpu.py"), "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
-                        "-k", "test_conv_forward_dgrad_wgrad or test_conv_exact_integer_data or test_one_channel_stride2_wgrad"], env=env, capture_output=True, text=True, timeout=170, cwd=os.path.dirname(HERE))
+                        "-k", "test_conv_forward_dgrad_wgrad or test_conv_exact_integer_data or test_one_channel_stride2"], env=env, capture_output=True, text=True, timeout=170, cwd=os.path.dirname(HERE))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout

@@ -185,6 +185,63 @@ def test_one_channel_stride2_wgrad(dev, mode, case):
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", C1_CASES + [(2, (256, 256), 32, 32), (2, (64, 512), 16, 16)],
+                         ids=lambda c: "nd%d_%s_%d+%d" % (c[0], "x".join(map(str, c[1])), c[2], c[3]))
+def test_one_channel_stride2_forward_and_transposed(dev, mode, case):
+    """The two layers with one channel on the fine side, forward, against torch's CPU convolution in fp64.  1 -> C
+    convolution: fp32 image and weights in both modes (2e-5 of the largest output in fp32; in bf16 the bound is the
+    rounding of the stored output), epilogue statistics to 1e-4, two destinations.  C -> 1 transposed convolution: the
+    channel tensor and the weights are bf16 in bf16 mode (the oracle gets the same rounded values), the output fp32.  Small integers
+    make both exact."""
+    nd, sp, c1, c2 = case
+    dt = DT[mode]
+    n = c1 + c2
+    g = torch.Generator().manual_seed(5 + c1 + 3 * c2 + sp[-1])
+    nb = 2
+    csp = [v // 2 for v in sp]
+    conv = F.conv2d if nd == 2 else F.conv3d
+    convT = F.conv_transpose2d if nd == 2 else F.conv_transpose3d
+    for exact in (False, True):
+        if exact:
+            x = torch.randint(-4, 5, (nb, *sp), generator=g).float()
+            w = torch.randint(-2, 3, [n, 1] + [3] * nd, generator=g).float()
+            b = torch.randint(-3, 4, (n,), generator=g).float()
+            yin = torch.randint(-2, 3, (nb, n, *csp), generator=g).float()
+        else:
+            x = torch.randn(nb, *sp, generator=g)
+            w = torch.randn([n, 1] + [3] * nd, generator=g) / 3 ** (nd / 2)
+            b = torch.randn(n, generator=g)
+            yin = torch.randn(nb, n, *csp, generator=g)
+            if mode == "bf16":
+                yin = bf16_round(yin)
+        y_ref = conv(x[:, None].double(), w.double(), b.double(), stride=2, padding=1)
+        out, stats = ops.conv1_forward(x.to(dev), w.to(dev), b.to(dev), dtype=dt, split=c1 if c2 else None, want_stats=True)
+        torch.cuda.synchronize()
+        y = torch.cat([from_cl(t) for t in out], 1) if c2 else from_cl(out)
+        if exact:
+            assert y_ref.abs().max() < 256 and torch.equal(y.double(), y_ref)
+        else:
+            assert rel_err(y.double(), y_ref) < TOL_OUT[mode]
+            nob = y_ref - b.double().view(1, -1, *([1] * nd))
+            st = stats.cpu().sum(1)
+            assert rel_err(st[..., 0], nob.flatten(2).sum(-1)) < 1e-4 and rel_err(st[..., 1], (nob * nob).flatten(2).sum(-1)) < 1e-4
+
+        wt = bf16_round(w) if mode == "bf16" else w      # the bf16 kernel multiplies on the matrix cores: weights rounded like every packed weight
+        t_ref = convT(yin.double(), wt.double(), b[:1].double(), stride=2, padding=1, output_padding=1)[:, 0]
+        ya = to_cl(yin[:, :c1].contiguous(), dt, dev)
+        yb = to_cl(yin[:, c1:].contiguous(), dt, dev) if c2 else None
+        xo, tstats = ops.conv1_transposed(ya, w.to(dev), b[:1].to(dev), y2=yb, want_stats=True)
+        torch.cuda.synchronize()
+        if exact:
+            assert torch.equal(xo.cpu().double(), t_ref)
+        else:
+            assert rel_err(xo.cpu().double(), t_ref) < (2e-5 if mode == "fp32" else 2e-4)
+            nob = t_ref - float(b[0])
+            st = tstats.cpu().sum(1)[:, 0]
+            assert rel_err(st[:, 0], nob.flatten(1).sum(-1)) < 1e-4 and rel_err(st[:, 1], (nob * nob).flatten(1).sum(-1)) < 1e-4
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
 @pytest.mark.parametrize("nd,sp,c", [(2, (32, 32), 16), (2, (20, 12), 64), (3, (4, 6, 8), 32), (2, (16, 16), 256)])
 def test_instnorm_prelu_fwd_bwd(dev, mode, nd, sp, c):
     dt = DT[mode]

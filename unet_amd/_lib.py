@@ -127,6 +127,8 @@ PROTOTYPES = {
                                 C.POINTER(MiTensor), _P]),
     "mi_conv_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(MiConvDesc)]),
     "mi_conv_wgrad": (C.c_int, [C.POINTER(MiConvDesc), C.POINTER(MiTensor), C.POINTER(MiTensor), _P, _P, _P, _P]),
+    "mi_conv1_forward": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P, C.POINTER(MiTensor), _P, _P]),
+    "mi_conv1_transposed": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, C.c_int, C.POINTER(MiTensor), _P, _P, _P, _P, _P]),
     "mi_conv1_wgrad_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, _P]),
     "mi_conv1_wgrad": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, C.POINTER(MiTensor), _P, _P, _P, _P]),
     "mi_instnorm_prelu_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int, C.POINTER(MiTensor), _P, _P,

@@ -174,6 +174,32 @@ int mi_conv1_wgrad(int dtype, int ndim, int nb, const int32_t* fine_dims, int n,
     return launch_reduce_one(rd, (hipStream_t)stream);
 }
 
+int mi_conv1_forward(int dtype, int ndim, int nb, const int32_t* fine_dims, int n, const float* x, const float* w,
+                     const float* bias, const mi_tensor* y, double* stats, void* stream) {
+    MI_CHECK(dtype == 0 || dtype == 1, "dtype must be 0 or 1");
+    MI_CHECK(x && w && y && y->ptr, "null argument");
+    C1Params p;
+    if (int r = conv1_geometry(ndim, nb, fine_dims, n, p)) return r;
+    p.x1 = x; p.w = w; p.n_w1 = n; p.bias = bias; p.bias_c0 = 0;
+    p.y_out = (char*)y->ptr; p.y_pitch = y->pitch; p.y_coff = y->coff; p.n_o1 = n;
+    if (y->ptr2) { p.y2_out = (char*)y->ptr2; p.y2o_pitch = y->pitch2; p.y2o_coff = y->coff2; p.n_o1 = y->c1; }
+    if (stats) { p.stats = stats; p.stats_c = n; p.nstat = n; }
+    return launch_c1_s2_fwd(dtype, p, (hipStream_t)stream);
+}
+
+int mi_conv1_transposed(int dtype, int ndim, int nb, const int32_t* fine_dims, int n, const mi_tensor* y, const float* w,
+                        const float* bias, float* x_out, double* stats, void* stream) {
+    MI_CHECK(dtype == 0 || dtype == 1, "dtype must be 0 or 1");
+    MI_CHECK(y && y->ptr && w && x_out, "null argument");
+    C1Params p;
+    if (int r = conv1_geometry(ndim, nb, fine_dims, n, p)) return r;
+    p.x1_out = x_out; p.w = w; p.bias = bias;
+    p.y = (const char*)y->ptr; p.y_pitch = y->pitch; p.y_coff = y->coff; p.n_y1 = n;
+    if (y->ptr2) { p.y2 = (const char*)y->ptr2; p.y2_pitch = y->pitch2; p.y2_coff = y->coff2; p.n_y1 = y->c1; }
+    if (stats) { p.stats = stats; p.stats_c = 1; p.nstat = 1; }
+    return launch_c1_s2_T(dtype, p, (hipStream_t)stream);
+}
+
 static void fill_drop(NormParams& p, float dropout, uint64_t seed, uint32_t layer) {
     p.seed = seed; p.layer = layer;
     norm_set_dropout(p, dropout);

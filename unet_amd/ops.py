@@ -98,6 +98,51 @@ def conv_wgrad(x, dy, w_shape, ksize=3, stride=1, transposed=False):
     return dw, db
 
 
+def _dims3(sp):
+    return (C.c_int32 * 3)(*([1] * (3 - len(sp)) + [int(v) for v in sp]))
+
+
+def conv1_forward(x, w, bias=None, dtype=torch.float32, split=None, want_stats=False):
+    """F.conv (k 3, stride 2, padding 1) of a one-channel fp32 tensor ``x`` [N, (D,) H, W] with ``w`` [C, 1, 3, ..]:
+    channels-last result of ``dtype``; ``split``: write the channels from ``split`` on to a second tensor (returned as
+    a pair).  With ``want_stats`` also the [N, 8, C, 2] fp64 sums of the bias-free result."""
+    lib = _lib.load()
+    nd, n = x.dim() - 1, w.shape[0]
+    osp = [v // 2 for v in x.shape[1:]]
+    c1 = n if split is None else split
+    y = torch.empty([x.shape[0]] + osp + [c1], dtype=dtype, device=x.device)
+    y2 = torch.empty([x.shape[0]] + osp + [n - c1], dtype=dtype, device=x.device) if split is not None else None
+    ty = _ten(y)
+    if y2 is not None:
+        ty.ptr2, ty.pitch2, ty.coff2, ty.c1 = y2.data_ptr(), y2.shape[-1], 0, c1
+    stats = torch.zeros(x.shape[0], 8, n, 2, dtype=torch.float64, device=x.device) if want_stats else None
+    wf = w.contiguous().float()
+    b = bias.contiguous().float() if bias is not None else None
+    _lib.check(lib.mi_conv1_forward(_DT[dtype], nd, x.shape[0], _dims3(x.shape[1:]), n, x.data_ptr(), wf.data_ptr(), _lib.ptr(b),
+                                    C.byref(ty), _lib.ptr(stats), _lib.current_stream(x.device)), "mi_conv1_forward")
+    out = y if y2 is None else (y, y2)
+    return (out, stats) if want_stats else out
+
+
+def conv1_transposed(y, w, bias=None, y2=None, want_stats=False):
+    """F.conv_transpose (k 3, stride 2, padding 1, output_padding 1) of channels-last ``y`` (+ ``y2``) with ``w``
+    [C, 1, 3, ..] to ONE output channel: fp32 [N, (D,) H, W] on the fine grid."""
+    lib = _lib.load()
+    nd = y.dim() - 2
+    n = y.shape[-1] + (y2.shape[-1] if y2 is not None else 0)
+    fsp = [2 * v for v in y.shape[1:-1]]
+    out = torch.empty([y.shape[0]] + fsp, dtype=torch.float32, device=y.device)
+    ty = _ten(y)
+    if y2 is not None:
+        ty.ptr2, ty.pitch2, ty.coff2, ty.c1 = y2.data_ptr(), y2.shape[-1], 0, y.shape[-1]
+    stats = torch.zeros(y.shape[0], 8, 1, 2, dtype=torch.float64, device=y.device) if want_stats else None
+    wf = w.contiguous().float()
+    b = bias.contiguous().float() if bias is not None else None
+    _lib.check(lib.mi_conv1_transposed(_DT[y.dtype], nd, y.shape[0], _dims3(fsp), n, C.byref(ty), wf.data_ptr(), _lib.ptr(b),
+                                       out.data_ptr(), _lib.ptr(stats), _lib.current_stream(y.device)), "mi_conv1_transposed")
+    return (out, stats) if want_stats else out
+
+
 def conv1_wgrad(x, y, y2=None):
     """Weight and bias gradient of the 3^d stride-2 convolution between a one-channel fp32 tensor ``x``
     ([N, (D,) H, W], fine grid) and channels-last ``y`` (coarse grid; ``y2``: a second source whose channels follow
@@ -105,7 +150,7 @@ def conv1_wgrad(x, y, y2=None):
     lib = _lib.load()
     nd = x.dim() - 1
     n = y.shape[-1] + (y2.shape[-1] if y2 is not None else 0)
-    dims = (C.c_int32 * 3)(*([1] * (3 - nd) + [int(v) for v in x.shape[1:]]))
+    dims = _dims3(x.shape[1:])
     ws = torch.empty(lib.mi_conv1_wgrad_workspace_bytes(nd, n, dims), dtype=torch.uint8, device=x.device)
     dw = torch.empty([n, 1] + [3] * nd, dtype=torch.float32, device=x.device)
     db = torch.empty(n, dtype=torch.float32, device=x.device)
