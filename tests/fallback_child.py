@@ -1,4 +1,4 @@
-"""Child process of tests/test_fallbacks_gpu.py: one bf16 forward + loss + backward of a small U-Net (2-D, or 3-D with CHILD_3D=1) under whatever
+"""Child process of tests/test_fallbacks_gpu.py: one bf16 forward + loss + backward of a small U-Net (2-D, 3-D with CHILD_3D=1, a larger 2-D batch with CHILD_BIG=1) under whatever
 kernel-family switches the environment holds (they are read once per process), results saved with torch.save."""
 import os
 import sys
@@ -23,6 +23,8 @@ def main(out_path: str) -> None:
         m = unet_amd.UNet(3, 1, 1, channels, (2, 2, 2), num_res_units=2, dropout=0.1, compute_dtype=dt).to(dev).train()
         m.seed_dropout(7)
         shape = (2, 1, 32, 48, 64)
+    if os.environ.get("CHILD_BIG"):      # a batch at which the large-workload schedule is chosen (16 slices of 256 x 256)
+        shape = (16, 1, 256, 256)
     x = torch.rand(*shape, generator=g).to(dev)
     t = (torch.rand(*shape, generator=g) > 0.7).float().to(dev)
     y = m(x)

@@ -26,13 +26,15 @@ SWITCHES = ["MI_NO_IGEMM_DMA", "MI_NO_IGEMM_DMA_S2", "MI_NO_CONV_DMA", "MI_NO_CO
 SWITCHES_3D = ["MI_NO_C1_MFMA3D", "MI_NO_CONV3D_K16", "MI_NO_IGEMM_DMA", "MI_NO_IGEMM_DMA_S2", "MI_NO_STENCIL3D_TILE", "MI_NO_FINISH_NORM"]
 
 
-def run_child(tmp_path, switch, three_d=False):
-    out = str(tmp_path / ((switch or "default") + ("_3d" if three_d else "") + ".pt"))
-    env = {k: v for k, v in os.environ.items() if not k.startswith("MI_NO_") and k != "CHILD_3D"}
+def run_child(tmp_path, switch, three_d=False, big=False):
+    out = str(tmp_path / ((switch or "default") + ("_3d" if three_d else "") + ("_big" if big else "") + ".pt"))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("MI_NO_") and k not in ("CHILD_3D", "CHILD_BIG")}
     if switch:
         env[switch] = "1"
     if three_d:
         env["CHILD_3D"] = "1"
+    if big:
+        env["CHILD_BIG"] = "1"
     r = subprocess.run([sys.executable, os.path.join(HERE, "fallback_child.py"), out], env=env, capture_output=True, text=True, timeout=110)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     return torch.load(out, weights_only=True)
@@ -73,6 +75,17 @@ def test_older_3d_kernels_agree_with_the_default_selection(tmp_path, baseline_3d
         d = got["grads"][k]
         ok = rel_l2(d, g) < 0.15 or float((d - g).abs().max()) < 5e-3 * scale
         assert ok, (k, rel_l2(d, g), float((d - g).abs().max()), scale)
+
+
+@pytest.mark.parametrize("switch", ["MI_NO_TAIL_ON_MAIN", "MI_NO_SIDE_STREAM"])
+def test_schedules_of_a_large_batch_agree_bit_for_bit(tmp_path, dev, switch):
+    """Where the kernels run (side stream or not, the end of the backward pass on the main stream or not) changes no
+    arithmetic: logits, loss and every gradient of a 16 x 256 x 256 batch are identical to the default schedule's."""
+    base = run_child(tmp_path, None, big=True)
+    got = run_child(tmp_path, switch, big=True)
+    assert torch.equal(got["logits"], base["logits"]) and got["loss"] == base["loss"]
+    for k, g in base["grads"].items():
+        assert torch.equal(got["grads"][k], g), k
 
 
 KERNEL_SWITCHES = [s for s in SWITCHES + ["MI_NO_C1_MFMA3D", "MI_NO_CONV3D_K16", "MI_NO_STENCIL3D_TILE"] if s not in ("MI_NO_SIDE_STREAM", "MI_NO_NORM_ON_LOAD", "MI_NO_FINISH_NORM", "MI_NO_FLAG_FORK")]
