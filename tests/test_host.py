@@ -367,3 +367,25 @@ def test_optimizer_parameter_list_is_checked_once_and_reused():
         unet_amd.AdamW(list(m.parameters())[:-1], lr=1e-3, model=m)._params_of(m)
     with pytest.raises(RuntimeError):
         opt.bind(other)._params_of(other)                    # another model's parameters
+
+
+def test_one_channel_operator_arguments_are_checked_on_the_host():
+    """The entry points of the two layers with one channel on the fine side refuse bad geometry before any launch
+    (no GPU involved): the workspace size is 0 and the call returns an error with a message."""
+    lib = _lib.load()
+    dims3 = lambda *v: (ctypes.c_int32 * 3)(*v)
+    # [slabs][27 taps + bias][32 channels] fp32 in 3-D, [slabs][9 + 1][32] in 2-D
+    assert lib.mi_conv1_wgrad_workspace_bytes(3, 32, dims3(96, 96, 96)) >= 768 * 28 * 32 * 4
+    assert lib.mi_conv1_wgrad_workspace_bytes(2, 32, dims3(1, 512, 512)) % 4 == 0
+    assert lib.mi_conv1_wgrad_workspace_bytes(2, 32, dims3(2, 512, 512)) == 0      # 2-D: depth must be 1
+    assert lib.mi_conv1_wgrad_workspace_bytes(3, 32, dims3(96, 95, 96)) == 0       # odd size under stride 2
+    assert lib.mi_conv1_wgrad_workspace_bytes(3, 12, dims3(96, 96, 96)) == 0       # channels not a multiple of 8
+    assert lib.mi_conv1_wgrad_workspace_bytes(4, 32, dims3(96, 96, 96)) == 0
+    t = _lib.MiTensor()
+    t.ptr, t.pitch, t.coff = 256, 32, 0      # never dereferenced: every call below fails in its checks
+    assert lib.mi_conv1_forward(0, 3, 1, dims3(8, 7, 8), 32, 256, 256, None, ctypes.byref(t), None, None) != 0
+    assert b"odd size" in lib.mi_last_error()
+    assert lib.mi_conv1_transposed(2, 3, 1, dims3(8, 8, 8), 32, ctypes.byref(t), 256, None, 256, None, None) != 0
+    assert b"dtype" in lib.mi_last_error()
+    assert lib.mi_conv1_wgrad(0, 3, 1, dims3(8, 8, 8), 32, None, ctypes.byref(t), 256, None, 256, None) != 0
+    assert b"null" in lib.mi_last_error()
