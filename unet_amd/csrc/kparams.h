@@ -79,6 +79,7 @@ struct ReduceDesc {
     signed char kidx[MI_MAX_TAPS + 1];
     float* dst_w; float* dst_b;             // dst_b may be null
     int blk0, nblk;                         // table launches: this descriptor owns workgroups [blk0, blk0 + nblk) of its launch
+    int tiled_max_slabs;                    // LDS-tiled form for at most this many slabs (0: never)
 };
 
 // Weight packing: dst[((t*Ntot + n_off + n)*Ktot + k_off + k)] = src[n*sn + k*sk + kidx[t]]
