@@ -2,6 +2,7 @@
 // transposed convolution (N -> 1, stride 2), their weight gradients, and the one-channel
 // 3^d stencil of the top residual unit.  All are bandwidth-bound VALU kernels; the
 // one-channel tensors are fp32 and share PyTorch's contiguous layout.
+#include <type_traits>
 #include "common.h"
 #include "kparams.h"
 
@@ -1227,22 +1228,26 @@ __global__ __launch_bounds__(256) void stencil_scalar_kernel(const StencilParams
 
 // partial[slab][k] = sum_p in[p + k - 1] * dout[p];  partial_bias[slab] = sum_p dout[p]
 // QUAD = 4: four consecutive pixels per thread and iteration (row length a multiple of 4); QUAD = 1: any length.
-template <int QUAD>
-__global__ __launch_bounds__(256) void stencil_wgrad_kernel(const StencilParams p) {
-    __shared__ float red[10][4];
-    const int KZ = p.ndim == 3 ? 3 : 1;
-    const int KK = KZ * 9;
-    const int kz = blockIdx.y;
+// All KZ planes of taps in one pass: dout is read once, the nine input rows of a pixel group are independent loads.
+template <int QUAD, int KZ, bool I64>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void stencil_wgrad_kernel(const StencilParams p) {   // four waves per SIMD: the 1024 workgroups of a launch are resident at once
+    constexpr int KK = KZ * 9;
+    __shared__ float red[KK + 1][4];
     const int qrow = p.d[2] / QUAD;
     const long long rows = (long long)p.nb * p.d[0] * p.d[1];
     const long long total = rows * qrow;
-    float acc[10];
+    const int lane = threadIdx.x & 63;
+    float acc[KK + 1];
 #pragma unroll
-    for (int k = 0; k < 10; ++k) acc[k] = 0.f;
-    for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long long)gridDim.x * 256) {
-        const int x0 = (int)(it % qrow) * QUAD; const long long row = it / qrow;
-        const int y = (int)(row % p.d[1]); const long long r2 = row / p.d[1];
-        const int z = (int)(r2 % p.d[0]);
+    for (int k = 0; k <= KK; ++k) acc[k] = 0.f;
+    typedef typename std::conditional<I64, long long, unsigned>::type idx_t;
+    for (idx_t it = (idx_t)blockIdx.x * 256 + threadIdx.x; it < (idx_t)total; it += (idx_t)gridDim.x * 256) {
+        const idx_t urow = it / (idx_t)qrow;
+        const int x0 = (int)(it - urow * (idx_t)qrow) * QUAD;
+        const idx_t r2 = urow / (idx_t)p.d[1];
+        const int y = (int)(urow - r2 * (idx_t)p.d[1]);
+        const int z = (int)(r2 % (idx_t)p.d[0]);
+        const long long row = (long long)urow;
         float g[QUAD];
         if constexpr (QUAD == 4) {
             const float4 t = *reinterpret_cast<const float4*>(p.dout + row * p.d[2] + x0);
@@ -1251,41 +1256,55 @@ __global__ __launch_bounds__(256) void stencil_wgrad_kernel(const StencilParams 
             g[0] = p.dout[row * p.d[2] + x0];
         }
 #pragma unroll
-        for (int j = 0; j < QUAD; ++j) acc[9] += g[j];
-        const int zz = (p.ndim == 3) ? z - 1 + kz : 0;
-        if ((unsigned)zz >= (unsigned)p.d[0]) continue;
-        const float* in = p.in + (row + (long long)(zz - z) * p.d[1] - y) * p.d[2];   // row 0 of plane zz of this image
+        for (int j = 0; j < QUAD; ++j) acc[KK] += g[j];
+        float v[KZ][3][QUAD + 2];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int yy = y - 1 + ky;
-            if ((unsigned)yy >= (unsigned)p.d[1]) continue;
-            const float* rp = in + (size_t)yy * p.d[2];
-            float v[QUAD + 2];
-            v[0] = x0 > 0 ? rp[x0 - 1] : 0.f;
-            if constexpr (QUAD == 4) {
-                const float4 c = *reinterpret_cast<const float4*>(rp + x0);
-                v[1] = c.x; v[2] = c.y; v[3] = c.z; v[4] = c.w;
-            } else {
-                v[1] = rp[x0];
+        for (int kz = 0; kz < KZ; ++kz) {
+            const int zz = KZ == 3 ? z - 1 + kz : 0;
+            const bool zok = (unsigned)zz < (unsigned)p.d[0];
+            const float* in = p.in + (row + (long long)((zok ? zz : z) - z) * p.d[1] - y) * p.d[2];   // row 0 of plane zz of this image
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int yy = y - 1 + ky;
+                const bool ok = zok && (unsigned)yy < (unsigned)p.d[1];
+                const float* rp = in + (size_t)(ok ? yy : y) * p.d[2];
+                if constexpr (QUAD == 4) {
+                    // the two neighbours along x are the next lanes' values (consecutive lanes are consecutive groups
+                    // of a row; at a row's ends the neighbour is outside the image); only the wave's end lanes load them
+                    const float4 c = ok ? *reinterpret_cast<const float4*>(rp + x0) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    v[kz][ky][1] = c.x; v[kz][ky][2] = c.y; v[kz][ky][3] = c.z; v[kz][ky][4] = c.w;
+                    float left = __shfl_up(c.w, 1, 64), right = __shfl_down(c.x, 1, 64);
+                    if (lane == 0 && ok && x0 > 0) left = rp[x0 - 1];
+                    if (lane == 63 && ok && x0 + QUAD < p.d[2]) right = rp[x0 + QUAD];
+                    v[kz][ky][0] = x0 > 0 ? left : 0.f;
+                    v[kz][ky][QUAD + 1] = x0 + QUAD < p.d[2] ? right : 0.f;
+                } else {
+                    v[kz][ky][0] = (ok && x0 > 0) ? rp[x0 - 1] : 0.f;
+                    v[kz][ky][1] = ok ? rp[x0] : 0.f;
+                    v[kz][ky][QUAD + 1] = (ok && x0 + QUAD < p.d[2]) ? rp[x0 + QUAD] : 0.f;
+                }
             }
-            v[QUAD + 1] = x0 + QUAD < p.d[2] ? rp[x0 + QUAD] : 0.f;
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-                for (int j = 0; j < QUAD; ++j) acc[ky * 3 + kx] += v[j + kx] * g[j];
         }
+#pragma unroll
+        for (int kz = 0; kz < KZ; ++kz)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int j = 0; j < QUAD; ++j) acc[(kz * 3 + ky) * 3 + kx] += v[kz][ky][j + kx] * g[j];
     }
     const int w = threadIdx.x >> 6;
 #pragma unroll
-    for (int k = 0; k < 10; ++k) {
+    for (int k = 0; k <= KK; ++k) {
         const float a = wave_sum(acc[k]);
         if ((threadIdx.x & 63) == 0) red[k][w] = a;
     }
     __syncthreads();
-    if (threadIdx.x < 10) {
+    if (threadIdx.x <= KK) {
         const float a = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
-        if (threadIdx.x < 9) p.partial[(size_t)blockIdx.x * KK + kz * 9 + threadIdx.x] = a;
-        else if (kz == 0) p.partial_bias[blockIdx.x] = a;
+        if (threadIdx.x < KK) p.partial[(size_t)blockIdx.x * KK + threadIdx.x] = a;
+        else p.partial_bias[blockIdx.x] = a;
     }
 }
 
@@ -1451,8 +1470,17 @@ int launch_stencil(const StencilParams& p, hipStream_t st) {
 }
 
 int launch_stencil_wgrad(const StencilParams& p, hipStream_t st) {
-    dim3 grid(p.nsplit, p.ndim == 3 ? 3 : 1);
-    if (p.d[2] % 4 == 0) hipLaunchKernelGGL(stencil_wgrad_kernel<4>, grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(stencil_wgrad_kernel<1>, grid, dim3(256), 0, st, p);
+    MI_CHECK((long long)p.nb * p.d[0] * p.d[1] * p.d[2] < (1ll << 31), "pixel count must stay below 2^31");
+    const dim3 grid(p.nsplit);
+    const bool quad = p.d[2] % 4 == 0;
+    // index arithmetic: 32-bit in 2-D (25.9 -> 24.1 us at 32 x 512^2); in 3-D the 64-bit form is the faster one
+    // (4 x 96^3: 29.5 us against 41-52 us: its long divisions stagger the waves' 28 loads, measured, not understood)
+    if (p.ndim == 3) {
+        if (quad) hipLaunchKernelGGL((stencil_wgrad_kernel<4, 3, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((stencil_wgrad_kernel<1, 3, true>), grid, dim3(256), 0, st, p);
+    } else {
+        if (quad) hipLaunchKernelGGL((stencil_wgrad_kernel<4, 1, false>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((stencil_wgrad_kernel<1, 1, false>), grid, dim3(256), 0, st, p);
+    }
     return check_launch("stencil_wgrad");
 }
