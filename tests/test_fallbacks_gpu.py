@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 SWITCHES = ["MI_NO_IGEMM_DMA", "MI_NO_IGEMM_DMA_S2", "MI_NO_CONV_DMA", "MI_NO_CONV_PHASE", "MI_NO_CONV_S2", "MI_NO_CONV_S2_STREAM", "MI_NO_CONV_K16", "MI_NO_WGRAD_DMA", "MI_NO_WGRAD_THICK",
             "MI_NO_WGRAD_THICK_S2", "MI_NO_WGRAD_THIN", "MI_NO_C1_STRIP", "MI_NO_SIDE_STREAM", "MI_NO_NORM_ON_LOAD", "MI_NO_FINISH_NORM", "MI_NO_FLAG_FORK",
-            "MI_NO_CONV_FLAG", "MI_NO_LATE_REDUCE", "MI_NO_REDUCE_TILED"]
+            "MI_NO_CONV_FLAG", "MI_NO_LATE_REDUCE", "MI_NO_REDUCE_TILED", "MI_NO_C1_MFMA2D"]
 
 
 # the families that only 3-D layers reach, run on a small 3-D network

@@ -134,6 +134,7 @@ C1_CASES = [
     (2, (32, 48), 16, 0),
     (2, (36, 20), 32, 0),
     (2, (24, 136), 16, 16),
+    (2, (40, 72), 32, 32),        # 64 channels from two sources (the first layer of the 32-512 network)
     (3, (8, 8, 8), 16, 0),
     (3, (12, 20, 72), 16, 0),     # 10 coarse rows (ragged four-row tiles), 36 coarse pixels per row (ragged 64-pixel tile)
     (3, (6, 36, 136), 16, 16),    # two sources; 68 coarse pixels: two tiles per row, the second nearly empty

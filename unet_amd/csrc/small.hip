@@ -837,7 +837,7 @@ __global__ __launch_bounds__(256) void c1_s2_wgrad_kernel(const C1Params p) {
         }
 }
 
-// ---- the same weight gradient in 3-D on the matrix cores (bf16 storage, N = 16 or 32) ---------------------------------
+// ---- the same weight gradient on the matrix cores (bf16 storage; 3-D: N = 16 or 32, 2-D (KZ = 1): N = 16, 32 or 64) ------
 // partial[slab][k][n] = sum_p Y[p][n] * x[p -> tap k] is a matrix product with the pixels as contraction: a wave takes
 // 32 consecutive coarse pixels of a row per MFMA step, rows = channels (Y loaded as 16-byte vectors and transposed
 // through LDS: two-byte loads of single channels cost a third of the kernel), columns = the 27 taps of all three kz
@@ -845,38 +845,39 @@ __global__ __launch_bounds__(256) void c1_s2_wgrad_kernel(const C1Params p) {
 // pixels, one row per wave; its image values (3 planes x 9 rows) are staged in LDS once and gathered per tap from there.  The image values are split into a bf16 head and
 // remainder (two products, fp32 accuracy as in c1_s2_fwd3d_mfma_kernel); Y is bf16 as stored.  The vector-ALU kernel
 // above runs once per kz plane, reads Y three times and spends 864 FMAs per pixel and channel group.
-template <int NB, int TX32>       // 16-channel blocks (N = 16 NB); 32-pixel units along x in a workgroup's tile (1 or 2)
+template <int NB, int TX32, int KZ>       // 16-channel blocks (N = 16 NB); 32-pixel units along x in a workgroup's tile (1 or 2); kernel planes (3, or 1 in 2-D)
 __global__ __launch_bounds__(256) void c1_s2_wgrad3d_mfma_kernel(const C1Params p) {
+    constexpr int KK = 9 * KZ, NTB = (KK + 1 + 15) / 16;       // taps; 16-column blocks holding the taps and the column of ones
     constexpr int N = 16 * NB, TY = 4, FY = 2 * TY + 1, FX = 64 * TX32 + 1;
     constexpr int PXP = 32 * TX32 + 8;               // pixels per channel row of the transposed Y (144 or 80 bytes: 16-byte aligned)
-    constexpr int TILE_B = 3 * FY * FX * 4, YSH_B = 4 * N * PXP * 2, RED_B = 4 * 32 * (N + 1) * 4;
+    constexpr int TILE_B = KZ * FY * FX * 4, YSH_B = 4 * N * PXP * 2, RED_B = 4 * 16 * NTB * (N + 1) * 4;
     __shared__ __align__(16) unsigned char smem[(TILE_B + 15) / 16 * 16 + YSH_B > RED_B ? (TILE_B + 15) / 16 * 16 + YSH_B : RED_B];
     unsigned* tile = reinterpret_cast<unsigned*>(smem);                       // image values of a tile: bf16 head | remainder << 16
     unsigned short* ysh = reinterpret_cast<unsigned short*>(smem + (TILE_B + 15) / 16 * 16);   // [wave][channel][pixel]
-    float (*red)[32][N + 1] = reinterpret_cast<float (*)[32][N + 1]>(smem);   // after the last tile
+    float (*red)[16 * NTB][N + 1] = reinterpret_cast<float (*)[16 * NTB][N + 1]>(smem);   // after the last tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, g = lane >> 4;
     const size_t fpix = (size_t)p.fd[0] * p.fd[1] * p.fd[2];
     const int ntx = (p.cd[2] + 32 * TX32 - 1) / (32 * TX32), nty = (p.cd[1] + TY - 1) / TY;
     const long long ntile = (long long)p.nb * p.cd[0] * nty * ntx;
-    // the lane's tap per column block: tile offset of (kz, ky, kx), or the ones column (27), or nothing (28 .. 31)
-    int toff[2], tkind[2];
+    // the lane's tap per column block: tile offset of (kz, ky, kx), or the ones column (KK), or nothing
+    int toff[NTB], tkind[NTB];
 #pragma unroll
-    for (int tb = 0; tb < 2; ++tb) {
+    for (int tb = 0; tb < NTB; ++tb) {
         const int k = tb * 16 + lr;
-        tkind[tb] = k < 27 ? 0 : k == 27 ? 1 : 2;
+        tkind[tb] = k < KK ? 0 : k == KK ? 1 : 2;
         const int kz = k / 9, r = k - kz * 9, ky = r / 3, kx = r - ky * 3;
-        toff[tb] = k < 27 ? (kz * FY + ky) * FX + kx : 0;
+        toff[tb] = k < KK ? (kz * FY + ky) * FX + kx : 0;
     }
-    v4f acc[NB][2];
+    v4f acc[NB][NTB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int tb = 0; tb < 2; ++tb) acc[nb][tb] = v4f{0.f, 0.f, 0.f, 0.f};
+        for (int tb = 0; tb < NTB; ++tb) acc[nb][tb] = v4f{0.f, 0.f, 0.f, 0.f};
 
     // A tile's global loads are requested one tile ahead (registers), so that their latency runs beside the previous
     // tile's LDS gathers and MFMAs; every load of a thread is in flight before its first LDS store.
-    constexpr int NR = (3 * FY + 3) / 4, NX = (FX + 63) / 64, NV = 32 * TX32 * N / 8 / 64;
+    constexpr int NR = (KZ * FY + 3) / 4, NX = (FX + 63) / 64, NV = 32 * TX32 * N / 8 / 64;
     float tv[NR][NX];
     uint4 yraw[NV];
     auto request = [&](long long t) {
@@ -885,13 +886,13 @@ __global__ __launch_bounds__(256) void c1_s2_wgrad3d_mfma_kernel(const C1Params 
         const int cz = (int)(r1 % p.cd[0]), img = (int)(r1 / p.cd[0]);
         const int cy0 = tyi * TY, cxt = txi * 32 * TX32;
         const float* xin = p.x1 + (size_t)img * fpix;
-        const int fz0 = 2 * cz - 1, fy0 = 2 * cy0 - 1, fx0 = 2 * cxt - 1;
+        const int fz0 = KZ == 3 ? 2 * cz - 1 : 0, fy0 = 2 * cy0 - 1, fx0 = 2 * cxt - 1;
 #pragma unroll
         for (int ri = 0; ri < NR; ++ri) {
             const int row = wave + 4 * ri;
             const int z = row / FY, y = row - z * FY;
             const int fz = fz0 + z, fy = fy0 + y;
-            const bool rok = row < 3 * FY && (unsigned)fz < (unsigned)p.fd[0] && (unsigned)fy < (unsigned)p.fd[1];
+            const bool rok = row < KZ * FY && (unsigned)fz < (unsigned)p.fd[0] && (unsigned)fy < (unsigned)p.fd[1];
             const float* src = xin + ((size_t)(rok ? fz : 0) * p.fd[1] + (rok ? fy : 0)) * p.fd[2];
 #pragma unroll
             for (int xi = 0; xi < NX; ++xi) {
@@ -923,7 +924,7 @@ __global__ __launch_bounds__(256) void c1_s2_wgrad3d_mfma_kernel(const C1Params 
 #pragma unroll
             for (int xi = 0; xi < NX; ++xi) {
                 const int x = lane + 64 * xi;
-                if (row < 3 * FY && x < FX) {
+                if (row < KZ * FY && x < FX) {
                     unsigned h, l;
                     split_bf16(tv[ri][xi], h, l);
                     tile[row * FX + x] = h | (l << 16);
@@ -944,13 +945,13 @@ __global__ __launch_bounds__(256) void c1_s2_wgrad3d_mfma_kernel(const C1Params 
         __syncthreads();
 #pragma unroll
         for (int xb = 0; xb < TX32; ++xb) {
-            uint4 afr[NB], bhi[2], blo[2];
+            uint4 afr[NB], bhi[NTB], blo[NTB];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
                 afr[nb] = *reinterpret_cast<const uint4*>(ysh + ((size_t)wave * N + nb * 16 + lr) * PXP + xb * 32 + 8 * g);
             const int base = (2 * wave) * FX + 2 * (xb * 32 + 8 * g);
 #pragma unroll
-            for (int tb = 0; tb < 2; ++tb) {
+            for (int tb = 0; tb < NTB; ++tb) {
                 unsigned t8[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -966,7 +967,7 @@ __global__ __launch_bounds__(256) void c1_s2_wgrad3d_mfma_kernel(const C1Params 
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                for (int tb = 0; tb < 2; ++tb) {
+                for (int tb = 0; tb < NTB; ++tb) {
                     acc[nb][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, afr[nb]), __builtin_bit_cast(v8bf, blo[tb]), acc[nb][tb], 0, 0, 0);
                     acc[nb][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, afr[nb]), __builtin_bit_cast(v8bf, bhi[tb]), acc[nb][tb], 0, 0, 0);
                 }
@@ -977,15 +978,15 @@ __global__ __launch_bounds__(256) void c1_s2_wgrad3d_mfma_kernel(const C1Params 
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int tb = 0; tb < 2; ++tb)
+        for (int tb = 0; tb < NTB; ++tb)
 #pragma unroll
             for (int j = 0; j < 4; ++j) red[wave][tb * 16 + lr][nb * 16 + 4 * g + j] = acc[nb][tb][j];
     __syncthreads();
     const size_t slab = blockIdx.x;
-    for (int i = tid; i < 28 * N; i += 256) {
+    for (int i = tid; i < (KK + 1) * N; i += 256) {
         const int k = i / N, n = i - k * N;
         const float a = ((red[0][k][n] + red[1][k][n]) + red[2][k][n]) + red[3][k][n];
-        if (k < 27) p.partial[(slab * 27 + k) * p.N + n] = a;
+        if (k < KK) p.partial[(slab * KK + k) * p.N + n] = a;
         else p.partial_bias[slab * p.N + n] = a;
     }
 }
@@ -1412,7 +1413,8 @@ int c1_wgrad_slabs(int N, const int cd[3]) {
 // whether launch_c1_s2_wgrad() takes the matrix-core kernel for these operands
 bool c1_wgrad3d_mfma_applicable(int dtype, const C1Params& p) {
     static const bool mfma = getenv("MI_NO_C1_MFMA3D") == nullptr;
-    return mfma && dtype && p.ndim == 3 && (p.N == 16 || p.N == 32) && p.n_y1 % 16 == 0 && p.y_pitch % 8 == 0 && p.y_coff % 8 == 0 &&
+    static const bool mfma2d = getenv("MI_NO_C1_MFMA2D") == nullptr;
+    return dtype && (p.ndim == 3 ? mfma && (p.N == 16 || p.N == 32) : mfma2d && (p.N == 16 || p.N == 32 || p.N == 64)) && p.n_y1 % 16 == 0 && p.y_pitch % 8 == 0 && p.y_coff % 8 == 0 &&
            (p.n_y1 >= p.N || (p.y2_pitch % 8 == 0 && p.y2_coff % 8 == 0));
 }
 
@@ -1423,10 +1425,16 @@ int launch_c1_s2_wgrad(int dtype, const C1Params& p, hipStream_t st) {
     MI_CHECK(p.nsplit == c1_wgrad_slabs(p.N, p.cd), "nsplit must come from c1_wgrad_slabs()");
     if (c1_wgrad3d_mfma_applicable(dtype, p)) {
         const bool wide = p.cd[2] > 32;
-        if (p.N == 16) { if (wide) hipLaunchKernelGGL((c1_s2_wgrad3d_mfma_kernel<1, 2>), dim3(p.nsplit), dim3(256), 0, st, p);
-                         else hipLaunchKernelGGL((c1_s2_wgrad3d_mfma_kernel<1, 1>), dim3(p.nsplit), dim3(256), 0, st, p); }
-        else { if (wide) hipLaunchKernelGGL((c1_s2_wgrad3d_mfma_kernel<2, 2>), dim3(p.nsplit), dim3(256), 0, st, p);
-               else hipLaunchKernelGGL((c1_s2_wgrad3d_mfma_kernel<2, 1>), dim3(p.nsplit), dim3(256), 0, st, p); }
+#define C1WM_CASE(NBV, TXV, KZV) hipLaunchKernelGGL((c1_s2_wgrad3d_mfma_kernel<NBV, TXV, KZV>), dim3(p.nsplit), dim3(256), 0, st, p)
+        if (p.ndim == 3) {
+            if (p.N == 16) { if (wide) C1WM_CASE(1, 2, 3); else C1WM_CASE(1, 1, 3); }
+            else { if (wide) C1WM_CASE(2, 2, 3); else C1WM_CASE(2, 1, 3); }
+        } else {
+            if (p.N == 16) { if (wide) C1WM_CASE(1, 2, 1); else C1WM_CASE(1, 1, 1); }
+            else if (p.N == 32) { if (wide) C1WM_CASE(2, 2, 1); else C1WM_CASE(2, 1, 1); }
+            else { if (wide) C1WM_CASE(4, 2, 1); else C1WM_CASE(4, 1, 1); }
+        }
+#undef C1WM_CASE
         return check_launch("c1_s2_wgrad3d_mfma");
     }
     const bool quad = p.N / C1_WGRAD_CG == 4;
